@@ -1,0 +1,73 @@
+"""ctypes binding of oracle/liboracle.so (the CPU checker).  Test infrastructure only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+dp = C.POINTER(C.c_double)
+
+
+def P(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(dp)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        L.orc_bc_func.restype = C.c_double
+        L.orc_bc_func.argtypes = [C.c_double] * 3
+        L.orc_fill_boundary.argtypes = [dp, C.c_int, C.c_double]
+        L.orc_coarse_matrix.argtypes = [dp, C.c_int, C.c_double]
+        L.orc_lu_factor.argtypes = [dp, C.c_int]
+        L.orc_lu_solve.argtypes = [dp, C.c_int, dp, dp]
+        L.orc_smooth_color.argtypes = [dp, dp, C.c_int, C.c_double, C.c_int]
+        L.orc_pre_smooth.argtypes = [dp, dp, C.c_int, C.c_double, C.c_int]
+        L.orc_post_smooth.argtypes = [dp, dp, C.c_int, C.c_double, C.c_int]
+        L.orc_residual.restype = C.c_double
+        L.orc_residual.argtypes = [dp, dp, C.c_int, C.c_double, dp]
+        L.orc_restrict.argtypes = [dp, C.c_int, dp, C.c_int]
+        L.orc_prolong.argtypes = [dp, C.c_int, dp, C.c_int]
+        L.orc_l2norm.restype = C.c_double
+        L.orc_l2norm.argtypes = [dp, C.c_long]
+        L.orc_vcycle.restype = C.c_double
+        L.orc_vcycle.argtypes = [C.POINTER(dp)] * 3 + [C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+        L.orc_run_problem.restype = C.c_double
+        L.orc_run_problem.argtypes = [C.c_int] * 5 + [dp, dp, dp]
+        L.orc_max_threads.restype = C.c_int
+        L.orc_set_threads.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def level_sizes(c, L):
+    return [(c - 1) * (1 << l) + 1 for l in range(L)]
+
+
+class Hierarchy:
+    """Three level hierarchies u, d, r as the reference allocates them (mg_3d.h:30-48)."""
+
+    def __init__(self, c, L):
+        self.c, self.L = c, L
+        self.N = level_sizes(c, L)
+        self.u = [np.zeros(n ** 3) for n in self.N]
+        self.d = [np.zeros(n ** 3) for n in self.N]
+        self.r = [np.zeros(n ** 3) for n in self.N]
+
+    def ptrs(self, xs):
+        return (dp * self.L)(*[P(a) for a in xs])
+
+
+def run_problem(c, L, nu, cycles, mode=0, want_u=True):
+    N = level_sizes(c, L)[-1]
+    norms = np.zeros(cycles)
+    u = np.zeros(N ** 3) if want_u else None
+    init = C.c_double(0)
+    secs = lib().orc_run_problem(c, L, nu, cycles, mode, P(norms), P(u) if want_u else None, C.byref(init))
+    return norms, u, init.value, secs
