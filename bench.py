@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- V-cycles/s of the MI355X multigrid V-cycle on the reference's own problem.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one V(nu,nu) cycle of the 3D Poisson problem test_mg_3d.c sets up (unit cube, RHS 0,
+Dirichlet u = x^2-2y^2+z^2 on the six faces, zero initial guess), device resident, through the C ABI
+of libmg3d.so (mg3d_vcycles).  Default workload: arguments `9 7 2` = 513^3 ("512^3"), V(2,2), fp64 --
+BASELINE.json configs[2].  Prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     : dominant kernel, algorithmic bytes per launch / its average duration measured with HIP
+                 events on the library's stream inside the timed region, against 8 TB/s HBM3E
+  cpu_baseline : the reference CPU path (oracle/_ref, kind "reference") or our CPU restatement
+                 (oracle/, kind "port") timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes_per_cycle(c, L, nu, w=8):
+    """per level [3(nu1+nu2)+7]*n*w + 3*n_c*w, plus (n0^2+2 n0)*w for the LU solve."""
+    tot = 0
+    for l in range(1, L):
+        n = ((c - 1) * (1 << l) + 1) ** 3
+        nc = ((c - 1) * (1 << (l - 1)) + 1) ** 3
+        tot += (3 * (nu + nu) + 7) * n * w + 3 * nc * w
+    n0 = c ** 3
+    return tot + (n0 * n0 + 2 * n0) * w
+
+
+def cpu_child(args):
+    """Runs in a fresh process so OMP_NUM_THREADS is honoured and no GPU runtime is loaded."""
+    import ctypes as C
+    import numpy as np
+    cores = len(os.sched_getaffinity(0))
+    ref = os.path.join(ROOT, "oracle", "_ref", "libmg3d_ref.so")
+    port = os.path.join(ROOT, "oracle", "liboracle.so")
+    dp = C.POINTER(C.c_double)
+    cycles = args.cpu_cycles
+    norms = np.zeros(cycles + 1)
+    if os.path.exists(ref) and not args.cpu_port:
+        lib = C.CDLL(ref)
+        lib.ref_run_problem.restype = C.c_double
+        lib.ref_run_problem.argtypes = [C.c_int] * 4 + [dp, dp, dp]
+        # 1 untimed warm-up cycle is part of the same loop; time = (cycles+1) cycles, report per cycle
+        secs = lib.ref_run_problem(args.coarse, args.levels, args.nu, cycles + 1, norms.ctypes.data_as(dp), None, None)
+        kind = "reference"
+    else:
+        if not os.path.exists(port):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], check=True,
+                           stdout=subprocess.DEVNULL)
+        lib = C.CDLL(port)
+        lib.orc_run_problem.restype = C.c_double
+        lib.orc_run_problem.argtypes = [C.c_int] * 5 + [dp, dp, dp]
+        secs = lib.orc_run_problem(args.coarse, args.levels, args.nu, cycles + 1, 0, norms.ctypes.data_as(dp), None,
+                                   None)
+        kind = "port"
+    N = (args.coarse - 1) * (1 << (args.levels - 1)) + 1
+    per = secs / (cycles + 1)
+    print(json.dumps({"value": 1.0 / per, "unit": "V-cycles/s", "cores": cores, "kind": kind,
+                      "sample": f"{cycles + 1} consecutive V({args.nu},{args.nu}) cycles of the same {N}^3 problem "
+                                f"(args {args.coarse} {args.levels} {args.nu}), OpenMP over all {cores} host cores, "
+                                f"omp_get_wtime around the cycle loop as test_mg_3d.c:36,68",
+                      "seconds_per_cycle": per, "last_norm": float(norms[cycles])}))
+
+
+def run_cpu_baseline(args):
+    env = dict(os.environ)
+    cores = len(os.sched_getaffinity(0))
+    env.update(OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", "--coarse", str(args.coarse), "--levels",
+           str(args.levels), "--nu", str(args.nu), "--cpu-cycles", str(args.cpu_cycles)]
+    if args.cpu_port:
+        cmd.append("--cpu-port")
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:  # the baseline is reported, never required
+        return {"value": None, "unit": "V-cycles/s", "cores": cores, "kind": "port", "sample": f"failed: {e}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--coarse", type=int, default=9)
+    ap.add_argument("--levels", type=int, default=7)
+    ap.add_argument("--nu", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cycles", type=int, default=8)
+    ap.add_argument("--cpu-port", action="store_true", help="time oracle/ (port) even if oracle/_ref exists")
+    ap.add_argument("--cpu-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--breakdown", action="store_true", help="print the per-level stage table to stderr")
+    args = ap.parse_args()
+    if args.cpu_child:
+        return cpu_child(args)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch  # first: libmg3d then shares torch's HIP runtime (same SONAME)
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import multigrid_parallel_amd as M
+    from multigrid_parallel_amd.binding import MG3D_U
+
+    c, L, nu = args.coarse, args.levels, args.nu
+    N = (c - 1) * (1 << (L - 1)) + 1
+    if world > 1:
+        sys.exit("bench.py: multi-GPU slab path not wired into this build yet")
+    solver = M.Solver(c, L, nu)
+    solver.setup_test_problem()
+    init = solver.get_initial_residual()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        solver.sync()
+        torch.cuda.synchronize()
+
+    solver.vcycles(args.warmup)
+    solver.timing_reset()
+    solver.timing_enable(2)  # event pairs around the finest-level stages only; no host stall
+    barrier()
+    t0 = time.perf_counter()
+    norms = solver.vcycles(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    solver.timing_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    tm = solver.timing()
+    fin = L - 1
+    sm_calls = tm[(fin, "Smoother1")][0] + tm[(fin, "Smoother2")][0]
+    sm_secs = tm[(fin, "Smoother1")][1] + tm[(fin, "Smoother2")][1]
+    n_f = N ** 3
+    info = M.lib().mg3d_kernel_info() if hasattr(M.lib(), "mg3d_kernel_info") else None
+    launches_per_call = 2 * nu  # colour passes per smoother call in the baseline kernel set
+    bytes_per_launch = 1.5 * n_f * 8  # full RB sweep = 3*n*w, one colour pass = half
+    dur = sm_secs / max(1, sm_calls * launches_per_call)
+    achieved = bytes_per_launch / dur / 1e9 if dur > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": "smooth_color_kernel (one red or black pass, finest level)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": dur * 1e3,
+            "launches_timed": sm_calls * launches_per_call}
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            roof["traffic"] = json.load(open(pmc)).get("smooth_color_kernel")
+        except Exception:
+            pass
+
+    if rank == 0:
+        alg = algorithmic_bytes_per_cycle(c, L, nu)
+        per_step = elapsed / args.steps
+        line = {
+            "metric": "V-cycles/sec, 513^3 ('512^3') Poisson, V(2,2), fp64" if (c, L, nu) == (9, 7, 2)
+            else f"V-cycles/sec, {N}^3 Poisson, V({nu},{nu}), fp64",
+            "value": args.steps / elapsed, "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{N}^3 Poisson (args {c} {L} {nu}), Dirichlet x^2-2y^2+z^2, V({nu},{nu}), "
+                                   f"device-resident, test_mg_3d.c problem", "coarse_pts": c, "levels": L,
+                       "smooth_iters": nu, "parallelism": f"{world} GPU" + ("" if world == 1 else " i-slabs")},
+            "vcycle_algorithmic_gb": alg / 1e9, "vcycle_algorithmic_gbs": alg / per_step / 1e9,
+            "vcycle_frac_of_hbm_peak": alg / per_step / 1e9 / HBM_PEAK_GBS,
+            "smoother_hbm_gbs": 3.0 * n_f * 8 * nu / (sm_secs / max(1, sm_calls)) / 1e9 if sm_secs > 0 else None,
+            "first_norm": float(norms[0]), "last_norm": float(norms[-1]), "initial_rhs_norm": init,
+            "roofline": roof,
+        }
+        if args.breakdown:
+            for (lvl, st), (calls, secs) in sorted(tm.items()):
+                if calls:
+                    print(f"level {lvl} {st:24s} calls {calls:5d}  {secs * 1e3 / calls:9.4f} ms/call", file=sys.stderr)
+        if not args.no_cpu_baseline and world == 1:
+            solver.finalize()
+            line["cpu_baseline"] = run_cpu_baseline(args)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

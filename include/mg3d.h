@@ -1,0 +1,140 @@
+/*
+ * mg3d.h -- C ABI of libmg3d.so, the MI355X (gfx950) implementation of the
+ * reference's 3D geometric-multigrid V-cycle (knram06/multigrid_parallel,
+ * mg_3d.h).  Plain C: opaque context, raw pointers, sizes, int status codes.
+ * No C++ exceptions, no torch types cross this boundary.
+ *
+ * The reference has no FFI; its boundary is textual inclusion of mg_3d.h
+ * (test_mg_3d.c:4-6).  include/mg_3d.h in this repo is the drop-in header
+ * whose functions forward to the entry points below.  Every entry point cites
+ * the reference definition it replaces (file:line under the reference tree).
+ *
+ * All grids are fp64, vertex centred, idx = N*N*i + N*j + k with k contiguous
+ * on the HOST side (mg_3d.h:43-44).  On the device every level is kept in a
+ * padded layout (k-pitch a multiple of 16 doubles); mg3d_upload/download
+ * convert.  There is NO CPU fallback: every compute entry point returns
+ * MG3D_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef MG3D_H
+#define MG3D_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mg3d_ctx mg3d_ctx;
+
+enum {
+    MG3D_OK = 0,
+    MG3D_ERR_ARG = 1,       /* bad argument (NULL, size, level out of range) */
+    MG3D_ERR_NO_DEVICE = 2, /* no HIP device: the product has no CPU path */
+    MG3D_ERR_HIP = 3,       /* a HIP runtime call failed; see mg3d_last_error() */
+    MG3D_ERR_ALLOC = 4,
+    MG3D_ERR_STATE = 5      /* e.g. V-cycle requested before the coarse LU was set */
+};
+
+/* fields of a level (mg_3d.h:26: double **u, **d, **r) */
+enum { MG3D_U = 0, MG3D_D = 1, MG3D_R = 2 };
+
+/* stages of the per-level timing table (mg_3d.h:136-137) */
+enum {
+    MG3D_ST_SMOOTH1 = 0, MG3D_ST_RESIDUAL1, MG3D_ST_RESTRICT, MG3D_ST_RECURSE,
+    MG3D_ST_PROLONG, MG3D_ST_SMOOTH2, MG3D_ST_RESIDUAL2, MG3D_NUM_STAGES
+};
+
+const char *mg3d_last_error(void);     /* thread-local text of the last failure */
+const char *mg3d_stage_name(int stage); /* "Smoother1", ... (mg_3d.h:136-137) */
+int mg3d_device_count(void);            /* 0 when no usable device */
+
+/* ------------------------------------------------------------------ context
+ * Replaces SolverInitialize's allocation (mg_3d.h:107-144, 30-48): three
+ * hierarchies u,d,r of num_levels levels, level l having
+ * ((coarse_pts-1)*2^l+1)^3 points, all zero; spacing = grid_length/(N-1). */
+int mg3d_ctx_create(int coarse_pts, int num_levels, int smooth_iters, double grid_length, mg3d_ctx **out);
+int mg3d_ctx_destroy(mg3d_ctx *ctx); /* SolverFinalize, mg_3d.h:1452-1467 */
+int mg3d_ctx_num_levels(const mg3d_ctx *ctx);
+int mg3d_ctx_level_n(const mg3d_ctx *ctx, int level); /* points per side, mg_3d.h:41 */
+double mg3d_ctx_level_h(const mg3d_ctx *ctx, int level);
+int mg3d_ctx_set_smooth_iters(mg3d_ctx *ctx, int iters);
+
+/* Coarsest operator.  mg3d_ctx_build_coarse = constructCoarseMatrixA +
+ * convertToLU_InPlace as SolverGetDetails does (mg_3d.h:282-289), with the
+ * spacing the caller chooses (mg_3d.h:287 passes h*2^(L-1);
+ * test_mg_3d_dirichlet.c:40 passes the finest h).  mg3d_ctx_set_lu installs a
+ * caller-factored row-major LU (n = coarse_pts^3) instead. */
+int mg3d_ctx_build_coarse(mg3d_ctx *ctx, double h_coarse);
+int mg3d_ctx_set_lu(mg3d_ctx *ctx, const double *LU);
+
+/* ------------------------------------------------------------ data movement
+ * Host arrays are dense N^3 (reference layout). */
+int mg3d_upload(mg3d_ctx *ctx, int field, int level, const double *host);
+int mg3d_download(mg3d_ctx *ctx, int field, int level, double *host);
+int mg3d_zero(mg3d_ctx *ctx, int field, int level); /* memset of mg_3d.h:1258-1259 */
+int mg3d_sync(mg3d_ctx *ctx);
+/* raw device view of a level for callers that share device memory (tests, bench) */
+int mg3d_device_view(mg3d_ctx *ctx, int field, int level, void **dev_ptr, int *pitch_doubles, long *plane_doubles);
+
+/* ------------------------------------------------ operators on device levels
+ * mg3d_smooth     : preSmoother (post=0, mg_3d.h:640-709: iters x red,black)
+ *                   postSmoother (post=1, mg_3d.h:711-781: iters x black,red)
+ * mg3d_residual   : calculateResidual (mg_3d.h:794-842); store!=0 writes r on
+ *                   the interior; *norm = sqrt(sum diff^2) (may be NULL)
+ * mg3d_restrict   : restrictResidual r[level] -> d[level-1] (mg_3d.h:844-998)
+ * mg3d_prolong    : prolongateAndCorrectError u[level-1] -> u[level] (mg_3d.h:1000-1145)
+ * mg3d_coarse_solve: solveWithLU(LU, n, d[0], u[0]) (gauss_elim.h:31-60)
+ * mg3d_l2norm     : GetL2NormOfVector over all N^3 entries (mg_3d.h:783-792) */
+int mg3d_smooth(mg3d_ctx *ctx, int level, int post, int iters);
+int mg3d_residual(mg3d_ctx *ctx, int level, int store, double *norm);
+int mg3d_restrict(mg3d_ctx *ctx, int level);
+int mg3d_prolong(mg3d_ctx *ctx, int level);
+int mg3d_coarse_solve(mg3d_ctx *ctx);
+int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm);
+
+/* One V-cycle from `level` down (vcycle, mg_3d.h:1242-1362); *norm receives the
+ * post-smoothing residual norm of `level` (the value SolverLinSolve returns,
+ * mg_3d.h:1415-1420).  mg3d_vcycles runs `count` cycles from the finest level
+ * back to back with a single host synchronisation at the end. */
+int mg3d_vcycle(mg3d_ctx *ctx, int level, double *norm);
+int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms);
+
+/* per-stage timers (timing_info.h:6-47), filled from hipEvent pairs recorded in-stream (no stall).
+ * on: 0 = off, 1 = every level, 2 = finest level only. */
+int mg3d_timing_enable(mg3d_ctx *ctx, int on);
+int mg3d_timing_reset(mg3d_ctx *ctx);
+int mg3d_timing_get(mg3d_ctx *ctx, int level, int stage, int *num_calls, double *seconds);
+
+/* ------------------------------------- host-pointer forms (reference signatures)
+ * Same argument meaning as the reference functions; data is staged to the
+ * device, computed there, and copied back.  They exist so that drivers that
+ * call the operators directly (test_mg_3d_dirichlet.c:51,60) link unchanged. */
+int mg3d_host_smooth(double *v, const double *d, int N, double h, int iters, int post);
+int mg3d_host_residual(const double *v, const double *d, int N, double h, double *res, double *norm);
+int mg3d_host_restrict(const double *r, int Nf, double *dc, int Nc);
+int mg3d_host_prolong(const double *ec, int Nc, double *ef, int Nf);
+int mg3d_host_lu_solve(const double *LU, int n, const double *b, double *x);
+/* vcycle(u,f,res,h,q,numLevels,smootherIter,N,LU), mg_3d.h:1242: caller-owned
+ * host hierarchies (allocGridLevels).  Levels 0..q are copied back after the cycle. */
+int mg3d_host_vcycle(double **u, double **f, double **res, double h, int q, int num_levels, int iters, int N,
+                     const double *LU, double *norm);
+
+/* --------------------------------------------------- host-only helpers (no device)
+ * mg3d_bc_func            : BCFunc (mg_3d.h:89-90)
+ * mg3d_fill_boundary_host : setupBoundaryConditions (mg_3d.h:1147-1239)
+ * mg3d_coarse_matrix      : constructCoarseMatrixA (mg_3d.h:147-273), A zeroed by caller
+ * mg3d_lu_factor          : convertToLU_InPlace (gauss_elim.h:9-29)
+ * mg3d_lu_solve_host      : NOT provided -- the solve runs on the device only
+ * mg3d_l2norm_host        : GetL2NormOfVector (mg_3d.h:783-792)
+ * mg3d_smooth_edges_host  : updateEdgeValues (mg_3d.h:304-430; cosmetic, never read by the stencil)
+ * mg3d_write_vtk          : writeOutputData (postprocess.h:5-47) */
+double mg3d_bc_func(double x, double y, double z);
+void mg3d_fill_boundary_host(double *v, int N, double h);
+void mg3d_coarse_matrix(double *A, int N, double h);
+void mg3d_lu_factor(double *a, int n);
+double mg3d_l2norm_host(const double *d, long n);
+void mg3d_smooth_edges_host(double *u, int N);
+int mg3d_write_vtk(const char *file_name, const double *grid, double h, int N);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MG3D_H */

@@ -1,0 +1,252 @@
+"""ctypes mirror of include/mg3d.h plus a `Solver` class that follows the reference's Solver* facade
+(mg_3d.h:107-144, 275-293, 1412-1467).  No compute happens here; every call goes into libmg3d.so and
+raises `Mg3dError` when the library (or a GPU) is missing -- there is no CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+dp = C.POINTER(C.c_double)
+
+MG3D_U, MG3D_D, MG3D_R = 0, 1, 2
+STAGES = 7
+_ERR = {1: "bad argument", 2: "no device", 3: "HIP error", 4: "allocation failed", 5: "bad state"}
+
+
+class Mg3dError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mg3d error {code} ({_ERR.get(code, '?')}): {msg}")
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libmg3d.so")
+
+
+_lib = None
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against include/mg3d.h
+SIGNATURES = {
+    "mg3d_last_error": (C.c_char_p, []),
+    "mg3d_stage_name": (C.c_char_p, [C.c_int]),
+    "mg3d_device_count": (C.c_int, []),
+    "mg3d_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_void_p)]),
+    "mg3d_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "mg3d_ctx_num_levels": (C.c_int, [C.c_void_p]),
+    "mg3d_ctx_level_n": (C.c_int, [C.c_void_p, C.c_int]),
+    "mg3d_ctx_level_h": (C.c_double, [C.c_void_p, C.c_int]),
+    "mg3d_ctx_set_smooth_iters": (C.c_int, [C.c_void_p, C.c_int]),
+    "mg3d_ctx_build_coarse": (C.c_int, [C.c_void_p, C.c_double]),
+    "mg3d_ctx_set_lu": (C.c_int, [C.c_void_p, dp]),
+    "mg3d_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
+    "mg3d_download": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
+    "mg3d_zero": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mg3d_sync": (C.c_int, [C.c_void_p]),
+    "mg3d_device_view": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_long)]),
+    "mg3d_smooth": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mg3d_residual": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
+    "mg3d_restrict": (C.c_int, [C.c_void_p, C.c_int]),
+    "mg3d_prolong": (C.c_int, [C.c_void_p, C.c_int]),
+    "mg3d_coarse_solve": (C.c_int, [C.c_void_p]),
+    "mg3d_l2norm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
+    "mg3d_vcycle": (C.c_int, [C.c_void_p, C.c_int, dp]),
+    "mg3d_vcycles": (C.c_int, [C.c_void_p, C.c_int, dp]),
+    "mg3d_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "mg3d_timing_reset": (C.c_int, [C.c_void_p]),
+    "mg3d_timing_get": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), dp]),
+    "mg3d_host_smooth": (C.c_int, [dp, dp, C.c_int, C.c_double, C.c_int, C.c_int]),
+    "mg3d_host_residual": (C.c_int, [dp, dp, C.c_int, C.c_double, dp, dp]),
+    "mg3d_host_restrict": (C.c_int, [dp, C.c_int, dp, C.c_int]),
+    "mg3d_host_prolong": (C.c_int, [dp, C.c_int, dp, C.c_int]),
+    "mg3d_host_lu_solve": (C.c_int, [dp, C.c_int, dp, dp]),
+    "mg3d_host_vcycle": (C.c_int, [C.POINTER(dp), C.POINTER(dp), C.POINTER(dp), C.c_double, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, dp, dp]),
+    "mg3d_bc_func": (C.c_double, [C.c_double, C.c_double, C.c_double]),
+    "mg3d_fill_boundary_host": (None, [dp, C.c_int, C.c_double]),
+    "mg3d_coarse_matrix": (None, [dp, C.c_int, C.c_double]),
+    "mg3d_lu_factor": (None, [dp, C.c_int]),
+    "mg3d_l2norm_host": (C.c_double, [dp, C.c_long]),
+    "mg3d_smooth_edges_host": (None, [dp, C.c_int]),
+    "mg3d_write_vtk": (C.c_int, [C.c_char_p, dp, C.c_double, C.c_int]),
+}
+
+
+def lib():
+    """Load libmg3d.so (built in-tree by `make -C multigrid_parallel_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise Mg3dError(2, f"{path} not built; run __graft_entry__.build() (there is no CPU fallback)")
+        L = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def P(a):
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], "need contiguous float64"
+    return a.ctypes.data_as(dp)
+
+
+def check(rc):
+    if rc != 0:
+        raise Mg3dError(rc, lib().mg3d_last_error().decode(errors="replace"))
+
+
+class Solver:
+    """Device-resident solver context.  Method names follow the reference facade:
+
+    Solver(c, L, nu)                     ~ SolverInitialize(argv = c, L, nu)      mg_3d.h:107
+    get_details()                        ~ SolverGetDetails (N, h; builds the LU)   mg_3d.h:275
+    setup_boundary_conditions()          ~ SolverSetupBoundaryConditions            mg_3d.h:1412
+    get_initial_residual()               ~ SolverGetInitialResidual                 mg_3d.h:1430
+    lin_solve()                          ~ SolverLinSolve (one V-cycle, its norm)   mg_3d.h:1415
+    get_residual()                       ~ SolverGetResidual                        mg_3d.h:1425
+    finalize()                           ~ SolverFinalize                           mg_3d.h:1452
+    """
+
+    def __init__(self, coarse_pts, num_levels, smooth_iters, grid_length=1.0):
+        self._h = C.c_void_p()
+        self.L = lib()
+        check(self.L.mg3d_ctx_create(coarse_pts, num_levels, smooth_iters, grid_length, C.byref(self._h)))
+        self.c, self.num_levels, self.nu = coarse_pts, num_levels, smooth_iters
+        self.N = self.L.mg3d_ctx_level_n(self._h, num_levels - 1)
+        self.h = self.L.mg3d_ctx_level_h(self._h, num_levels - 1)
+
+    # -- lifetime
+    def finalize(self):
+        if self._h:
+            check(self.L.mg3d_ctx_destroy(self._h))
+            self._h = C.c_void_p()
+
+    close = finalize
+
+    def __del__(self):
+        try:
+            self.finalize()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.finalize()
+
+    # -- geometry
+    def level_n(self, level):
+        return self.L.mg3d_ctx_level_n(self._h, level)
+
+    def level_h(self, level):
+        return self.L.mg3d_ctx_level_h(self._h, level)
+
+    # -- facade
+    def get_details(self, coarse_h=None):
+        """Builds + factors the coarsest operator with spacing h*2^(L-1) (mg_3d.h:287) unless given."""
+        ch = self.h * (1 << (self.num_levels - 1)) if coarse_h is None else coarse_h
+        check(self.L.mg3d_ctx_build_coarse(self._h, ch))
+        return self.N, self.h
+
+    def set_lu(self, LU):
+        check(self.L.mg3d_ctx_set_lu(self._h, P(LU)))
+
+    def setup_boundary_conditions(self, field=MG3D_D, level=None):
+        level = self.num_levels - 1 if level is None else level
+        n = self.level_n(level)
+        a = self.download(field, level)
+        self.L.mg3d_fill_boundary_host(P(a), n, self.level_h(level))
+        self.upload(field, level, a)
+
+    def setup_test_problem(self):
+        """test_mg_3d.c:11-29: BC values on the faces of d and of u, interior zero."""
+        self.get_details()
+        self.zero(MG3D_U, self.num_levels - 1)
+        self.zero(MG3D_D, self.num_levels - 1)
+        self.setup_boundary_conditions(MG3D_D)
+        self.setup_boundary_conditions(MG3D_U)
+
+    def get_initial_residual(self):
+        return self.l2norm(MG3D_D, self.num_levels - 1)
+
+    def lin_solve(self):
+        return self.vcycle(self.num_levels - 1)
+
+    def get_residual(self):
+        return self.residual(self.num_levels - 1, store=False)
+
+    # -- data
+    def upload(self, field, level, host):
+        n = self.level_n(level)
+        host = np.ascontiguousarray(host, dtype=np.float64).reshape(-1)
+        assert host.size == n ** 3
+        check(self.L.mg3d_upload(self._h, field, level, P(host)))
+
+    def download(self, field, level):
+        n = self.level_n(level)
+        out = np.empty(n ** 3)
+        check(self.L.mg3d_download(self._h, field, level, P(out)))
+        return out
+
+    def zero(self, field, level):
+        check(self.L.mg3d_zero(self._h, field, level))
+
+    def sync(self):
+        check(self.L.mg3d_sync(self._h))
+
+    # -- operators
+    def smooth(self, level, post, iters):
+        check(self.L.mg3d_smooth(self._h, level, int(post), iters))
+
+    def residual(self, level, store=True, want_norm=True):
+        nrm = C.c_double(0)
+        check(self.L.mg3d_residual(self._h, level, int(store), C.byref(nrm) if want_norm else None))
+        return nrm.value
+
+    def restrict(self, level):
+        check(self.L.mg3d_restrict(self._h, level))
+
+    def prolong(self, level):
+        check(self.L.mg3d_prolong(self._h, level))
+
+    def coarse_solve(self):
+        check(self.L.mg3d_coarse_solve(self._h))
+
+    def l2norm(self, field, level):
+        nrm = C.c_double(0)
+        check(self.L.mg3d_l2norm(self._h, field, level, C.byref(nrm)))
+        return nrm.value
+
+    def vcycle(self, level=None, want_norm=True):
+        level = self.num_levels - 1 if level is None else level
+        nrm = C.c_double(0)
+        check(self.L.mg3d_vcycle(self._h, level, C.byref(nrm) if want_norm else None))
+        return nrm.value
+
+    def vcycles(self, count):
+        norms = np.zeros(count)
+        check(self.L.mg3d_vcycles(self._h, count, P(norms)))
+        return norms
+
+    # -- timing
+    def timing_enable(self, on=True):
+        check(self.L.mg3d_timing_enable(self._h, int(on)))
+
+    def timing_reset(self):
+        check(self.L.mg3d_timing_reset(self._h))
+
+    def timing(self):
+        out = {}
+        for l in range(self.num_levels):
+            for s in range(STAGES):
+                calls, secs = C.c_int(0), C.c_double(0)
+                check(self.L.mg3d_timing_get(self._h, l, s, C.byref(calls), C.byref(secs)))
+                out[(l, self.L.mg3d_stage_name(s).decode())] = (calls.value, secs.value)
+        return out

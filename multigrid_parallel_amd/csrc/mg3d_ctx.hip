@@ -1,0 +1,813 @@
+/*
+ * mg3d_ctx.hip -- solver context and V-cycle sequencing behind the C ABI (include/mg3d.h).
+ *
+ * The context is the device-resident counterpart of the reference's global
+ * state (mg_3d.h:19-28): three level hierarchies u, d, r plus the factored
+ * coarsest operator.  Everything is enqueued on one HIP stream; the only host
+ * synchronisations are the ones an entry point's contract requires (returning
+ * a norm, copying data back).
+ */
+#include "mg3d_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+/* ------------------------------------------------------------------ errors */
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(call)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(MG3D_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,    \
+                        __LINE__);                                                                         \
+    } while (0)
+
+#define CHK(call)              \
+    do {                       \
+        int rc_ = (call);      \
+        if (rc_ != MG3D_OK)    \
+            return rc_;        \
+    } while (0)
+
+extern "C" const char *mg3d_last_error(void) { return g_err; }
+
+static const char *const kStageNames[MG3D_NUM_STAGES] = {"Smoother1",          "CalcResidual1", "Restrict Residual",
+                                                         "Recurse, Direct Solve", "Prolongate&Correct", "Smoother2",
+                                                         "CalcResidual2"}; /* mg_3d.h:136-137 */
+
+extern "C" const char *mg3d_stage_name(int stage)
+{
+    return (stage >= 0 && stage < MG3D_NUM_STAGES) ? kStageNames[stage] : "?";
+}
+
+extern "C" int mg3d_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+static int require_device(void)
+{
+    if (mg3d_device_count() <= 0)
+        return fail(MG3D_ERR_NO_DEVICE, "no HIP device available: libmg3d has no CPU fallback");
+    return MG3D_OK;
+}
+
+/* ----------------------------------------------------------------- context */
+struct Level {
+    Geom g;
+    double h;
+    size_t elems; /* doubles allocated per field */
+    double *f[3]; /* u, d, r */
+};
+
+struct StageTimer {
+    int calls;
+    double seconds;
+};
+
+struct mg3d_ctx {
+    int c, L, iters;
+    double length;
+    std::vector<Level> lv;
+    hipStream_t stream;
+    LuBand lu;
+    bool have_lu;
+    double *lu_work;  /* 2n doubles */
+    double *partials; /* MG3D_MAX_PARTIALS doubles */
+    double *sumsq;    /* device slots for squared norms */
+    int sumsq_slots;
+    double *h_sumsq;  /* pinned mirror */
+    int timing; /* 0 off, 1 every level, 2 finest level only */
+    std::vector<StageTimer> timers; /* [L][MG3D_NUM_STAGES] */
+    /* stage timing never stalls the stream: event pairs are recorded in-stream and
+     * resolved at the next host synchronisation the entry point does anyway */
+    struct Pending {
+        int level, stage;
+        hipEvent_t a, b;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+static hipEvent_t take_event(mg3d_ctx *ctx)
+{
+    hipEvent_t e = nullptr;
+    if (!ctx->event_pool.empty()) {
+        e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+        e = nullptr;
+    }
+    return e;
+}
+
+/* call only after the stream has been synchronised */
+static void resolve_timers(mg3d_ctx *ctx)
+{
+    for (auto &p : ctx->pending) {
+        float ms = 0.f;
+        if (p.a && p.b && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            StageTimer &t = ctx->timers[(size_t)p.level * MG3D_NUM_STAGES + p.stage];
+            t.calls++;
+            t.seconds += ms * 1e-3;
+        }
+        if (p.a)
+            ctx->event_pool.push_back(p.a);
+        if (p.b)
+            ctx->event_pool.push_back(p.b);
+    }
+    ctx->pending.clear();
+}
+
+static void free_lu(mg3d_ctx *ctx)
+{
+    if (ctx->lu.lcol)
+        (void)hipFree(ctx->lu.lcol);
+    if (ctx->lu.ucol)
+        (void)hipFree(ctx->lu.ucol);
+    if (ctx->lu.diag)
+        (void)hipFree(ctx->lu.diag);
+    if (ctx->lu_work)
+        (void)hipFree(ctx->lu_work);
+    memset(&ctx->lu, 0, sizeof ctx->lu);
+    ctx->lu_work = nullptr;
+    ctx->have_lu = false;
+}
+
+extern "C" int mg3d_ctx_destroy(mg3d_ctx *ctx)
+{
+    if (!ctx)
+        return MG3D_OK;
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    for (auto &l : ctx->lv)
+        for (int k = 0; k < 3; k++)
+            if (l.f[k])
+                (void)hipFree(l.f[k]);
+    free_lu(ctx);
+    if (ctx->partials)
+        (void)hipFree(ctx->partials);
+    if (ctx->sumsq)
+        (void)hipFree(ctx->sumsq);
+    if (ctx->h_sumsq)
+        (void)hipHostFree(ctx->h_sumsq);
+    resolve_timers(ctx);
+    for (hipEvent_t e : ctx->event_pool)
+        (void)hipEventDestroy(e);
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MG3D_OK;
+}
+
+static mg3d_ctx *ctx_new(int L, int iters)
+{
+    mg3d_ctx *ctx = new mg3d_ctx();
+    ctx->c = 0;
+    ctx->length = 0.;
+    ctx->L = L;
+    ctx->iters = iters;
+    ctx->have_lu = false;
+    memset(&ctx->lu, 0, sizeof ctx->lu);
+    ctx->lu_work = nullptr;
+    ctx->partials = ctx->sumsq = ctx->h_sumsq = nullptr;
+    ctx->sumsq_slots = 0;
+    ctx->stream = nullptr;
+    ctx->timing = 0;
+    ctx->timers.assign((size_t)L * MG3D_NUM_STAGES, StageTimer{0, 0.});
+    ctx->lv.resize(L);
+    for (auto &l : ctx->lv)
+        l.f[0] = l.f[1] = l.f[2] = nullptr;
+    return ctx;
+}
+
+static int ctx_create_sizes(const int *n_per_level, const double *h_per_level, int L, int iters, mg3d_ctx **out)
+{
+    CHK(require_device());
+    mg3d_ctx *ctx = ctx_new(L, iters);
+#define CTXCHK(call)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            int rc_ = fail(e_ == hipErrorOutOfMemory ? MG3D_ERR_ALLOC : MG3D_ERR_HIP, "%s failed: %s", \
+                           #call, hipGetErrorString(e_));                                                \
+            mg3d_ctx_destroy(ctx);                                                                       \
+            return rc_;                                                                                  \
+        }                                                                                                \
+    } while (0)
+    CTXCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (int l = 0; l < L; l++) {
+        Level &lev = ctx->lv[l];
+        const int N = n_per_level[l];
+        lev.g.N = N;
+        lev.g.ni = lev.g.nj = lev.g.nk = N;
+        lev.g.ig0 = 0;
+        lev.g.pitch = mg3d_pitch_for(N);
+        lev.g.plane = (long long)lev.g.pitch * N;
+        lev.h = h_per_level[l];
+        lev.elems = (size_t)lev.g.plane * N;
+        for (int k = 0; k < 3; k++) {
+            CTXCHK(hipMalloc(&lev.f[k], lev.elems * sizeof(double)));
+            CTXCHK(hipMemsetAsync(lev.f[k], 0, lev.elems * sizeof(double), ctx->stream)); /* calloc, mg_3d.h:44 */
+        }
+    }
+    CTXCHK(hipMalloc(&ctx->partials, MG3D_MAX_PARTIALS * sizeof(double)));
+    ctx->sumsq_slots = 1024;
+    CTXCHK(hipMalloc(&ctx->sumsq, ctx->sumsq_slots * sizeof(double)));
+    CTXCHK(hipHostMalloc(&ctx->h_sumsq, ctx->sumsq_slots * sizeof(double)));
+    CTXCHK(hipStreamSynchronize(ctx->stream));
+#undef CTXCHK
+    *out = ctx;
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_ctx_create(int coarse_pts, int num_levels, int smooth_iters, double grid_length, mg3d_ctx **out)
+{
+    if (!out || coarse_pts < 3 || num_levels < 1 || num_levels > 24 || smooth_iters < 0)
+        return fail(MG3D_ERR_ARG, "mg3d_ctx_create: bad arguments (c=%d L=%d iters=%d)", coarse_pts, num_levels,
+                    smooth_iters);
+    const long long finest = ((long long)(coarse_pts - 1) << (num_levels - 1)) + 1; /* mg_3d.h:126-127 */
+    if (finest > 2049)
+        return fail(MG3D_ERR_ARG, "mg3d_ctx_create: finest grid %lld^3 too large", finest);
+    std::vector<int> n(num_levels);
+    std::vector<double> h(num_levels);
+    const double spacing = grid_length / (double)(finest - 1); /* mg_3d.h:143 */
+    for (int l = 0; l < num_levels; l++) {
+        n[l] = (coarse_pts - 1) * (1 << l) + 1; /* mg_3d.h:41 */
+        h[l] = 0.;
+    }
+    /* spacing doubles per coarser level exactly as vcycle does (h_coarse = 2*h, mg_3d.h:1303) */
+    h[num_levels - 1] = spacing;
+    for (int l = num_levels - 2; l >= 0; l--)
+        h[l] = 2 * h[l + 1];
+    CHK(ctx_create_sizes(n.data(), h.data(), num_levels, smooth_iters, out));
+    (*out)->c = coarse_pts;
+    (*out)->length = grid_length;
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_ctx_num_levels(const mg3d_ctx *ctx) { return ctx ? ctx->L : 0; }
+extern "C" int mg3d_ctx_level_n(const mg3d_ctx *ctx, int level)
+{
+    return (ctx && level >= 0 && level < ctx->L) ? ctx->lv[level].g.N : 0;
+}
+extern "C" double mg3d_ctx_level_h(const mg3d_ctx *ctx, int level)
+{
+    return (ctx && level >= 0 && level < ctx->L) ? ctx->lv[level].h : 0.;
+}
+extern "C" int mg3d_ctx_set_smooth_iters(mg3d_ctx *ctx, int iters)
+{
+    if (!ctx || iters < 0)
+        return fail(MG3D_ERR_ARG, "mg3d_ctx_set_smooth_iters: bad arguments");
+    ctx->iters = iters;
+    return MG3D_OK;
+}
+
+/* --------------------------------------------------------------- coarse LU */
+/* Banded, column-major copy of a dense row-major LU factor for the device solve:
+ * bw = populated half bandwidth (max |i-j| with LU[i][j] != 0). */
+static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_doubles)
+{
+    int bw = 1;
+    for (long long i = 0; i < n; i++) {
+        const double *row = LU + i * n;
+        long long lo = 0, hi = n - 1;
+        while (lo < i && row[lo] == 0.)
+            lo++;
+        while (hi > i && row[hi] == 0.)
+            hi--;
+        if (i - lo > bw)
+            bw = (int)(i - lo);
+        if (hi - i > bw)
+            bw = (int)(hi - i);
+    }
+    std::vector<double> lcol((size_t)n * bw, 0.), ucol((size_t)n * bw, 0.), diag((size_t)n);
+    for (long long j = 0; j < n; j++) {
+        diag[j] = LU[j * n + j];
+        for (int t = 0; t < bw; t++) {
+            const long long il = j + 1 + t, iu = j - 1 - t;
+            if (il < n)
+                lcol[j * bw + t] = LU[il * n + j];
+            if (iu >= 0)
+                ucol[j * bw + t] = LU[iu * n + j];
+        }
+    }
+    free_lu(ctx);
+    ctx->lu.n = (int)n;
+    ctx->lu.bw = bw;
+    HIPCHK(hipMalloc(&ctx->lu.lcol, lcol.size() * sizeof(double)));
+    HIPCHK(hipMalloc(&ctx->lu.ucol, ucol.size() * sizeof(double)));
+    HIPCHK(hipMalloc(&ctx->lu.diag, diag.size() * sizeof(double)));
+    HIPCHK(hipMalloc(&ctx->lu_work, work_doubles * sizeof(double)));
+    HIPCHK(hipMemcpy(ctx->lu.lcol, lcol.data(), lcol.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->lu.ucol, ucol.data(), ucol.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->lu.diag, diag.data(), diag.size() * sizeof(double), hipMemcpyHostToDevice));
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_ctx_set_lu(mg3d_ctx *ctx, const double *LU)
+{
+    if (!ctx || !LU)
+        return fail(MG3D_ERR_ARG, "mg3d_ctx_set_lu: NULL argument");
+    const int N0 = ctx->lv[0].g.N;
+    const long long n = (long long)N0 * N0 * N0;
+    if (n * n >= 2147483647LL) /* assert(totalNodes*totalNodes < INT_MAX), mg_3d.h:163 */
+        return fail(MG3D_ERR_ARG, "mg3d_ctx_set_lu: coarse grid %d^3 too large for a dense factor", N0);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    CHK(install_lu(ctx, LU, n, 2 * (size_t)n));
+    ctx->have_lu = true;
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_ctx_build_coarse(mg3d_ctx *ctx, double h_coarse)
+{
+    if (!ctx)
+        return fail(MG3D_ERR_ARG, "mg3d_ctx_build_coarse: NULL context");
+    const int N0 = ctx->lv[0].g.N;
+    const long long n = (long long)N0 * N0 * N0;
+    if (n * n >= 2147483647LL)
+        return fail(MG3D_ERR_ARG, "mg3d_ctx_build_coarse: coarse grid %d^3 too large for a dense factor", N0);
+    double *A = (double *)calloc((size_t)(n * n), sizeof(double)); /* mg_3d.h:283 */
+    if (!A)
+        return fail(MG3D_ERR_ALLOC, "mg3d_ctx_build_coarse: out of host memory");
+    mg3d_coarse_matrix(A, N0, h_coarse); /* mg_3d.h:288 */
+    mg3d_lu_factor(A, (int)n);           /* mg_3d.h:289 */
+    const int rc = mg3d_ctx_set_lu(ctx, A);
+    free(A);
+    return rc;
+}
+
+/* ----------------------------------------------------------- data movement */
+static int check_field_level(const mg3d_ctx *ctx, int field, int level, const char *who)
+{
+    if (!ctx || field < 0 || field > 2 || level < 0 || level >= ctx->L)
+        return fail(MG3D_ERR_ARG, "%s: bad field/level (%d, %d)", who, field, level);
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_upload(mg3d_ctx *ctx, int field, int level, const double *host)
+{
+    CHK(check_field_level(ctx, field, level, "mg3d_upload"));
+    if (!host)
+        return fail(MG3D_ERR_ARG, "mg3d_upload: NULL host pointer");
+    const Level &l = ctx->lv[level];
+    const int N = l.g.N;
+    HIPCHK(hipMemcpy2DAsync(l.f[field], l.g.pitch * sizeof(double), host, N * sizeof(double), N * sizeof(double),
+                            (size_t)N * N, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_download(mg3d_ctx *ctx, int field, int level, double *host)
+{
+    CHK(check_field_level(ctx, field, level, "mg3d_download"));
+    if (!host)
+        return fail(MG3D_ERR_ARG, "mg3d_download: NULL host pointer");
+    const Level &l = ctx->lv[level];
+    const int N = l.g.N;
+    HIPCHK(hipMemcpy2DAsync(host, N * sizeof(double), l.f[field], l.g.pitch * sizeof(double), N * sizeof(double),
+                            (size_t)N * N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_zero(mg3d_ctx *ctx, int field, int level)
+{
+    CHK(check_field_level(ctx, field, level, "mg3d_zero"));
+    const Level &l = ctx->lv[level];
+    HIPCHK(hipMemsetAsync(l.f[field], 0, l.elems * sizeof(double), ctx->stream));
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_sync(mg3d_ctx *ctx)
+{
+    if (!ctx)
+        return fail(MG3D_ERR_ARG, "mg3d_sync: NULL context");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    resolve_timers(ctx);
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_device_view(mg3d_ctx *ctx, int field, int level, void **dev_ptr, int *pitch_doubles,
+                                long *plane_doubles)
+{
+    CHK(check_field_level(ctx, field, level, "mg3d_device_view"));
+    const Level &l = ctx->lv[level];
+    if (dev_ptr)
+        *dev_ptr = l.f[field];
+    if (pitch_doubles)
+        *pitch_doubles = l.g.pitch;
+    if (plane_doubles)
+        *plane_doubles = (long)l.g.plane;
+    return MG3D_OK;
+}
+
+/* ----------------------------------------------------------------- operators */
+static int launch_ok(const char *who)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(MG3D_ERR_HIP, "%s: kernel launch failed: %s", who, hipGetErrorString(e));
+    return MG3D_OK;
+}
+
+static int read_norm(mg3d_ctx *ctx, int slot, double *norm)
+{
+    if (!norm)
+        return MG3D_OK;
+    HIPCHK(hipMemcpyAsync(ctx->h_sumsq + slot, ctx->sumsq + slot, sizeof(double), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    resolve_timers(ctx);
+    *norm = sqrt(ctx->h_sumsq[slot]); /* mg_3d.h:841 */
+    return MG3D_OK;
+}
+
+static void enqueue_smooth(mg3d_ctx *ctx, int level, int post, int iters)
+{
+    const Level &l = ctx->lv[level];
+    const double hSq = l.h * l.h; /* mg_3d.h:644 */
+    for (int s = 0; s < iters; s++) {
+        /* pre: red then black (mg_3d.h:657-702); post: black then red (mg_3d.h:728-773) */
+        k_smooth_color(l.g, l.f[MG3D_U], l.f[MG3D_D], hSq, post ? 0 : 1, ctx->stream);
+        k_smooth_color(l.g, l.f[MG3D_U], l.f[MG3D_D], hSq, post ? 1 : 0, ctx->stream);
+    }
+}
+
+static void enqueue_residual(mg3d_ctx *ctx, int level, int store, int slot)
+{
+    const Level &l = ctx->lv[level];
+    const double invHsq = 1. / (l.h * l.h); /* mg_3d.h:797 */
+    k_residual(l.g, l.f[MG3D_U], l.f[MG3D_D], invHsq, store ? l.f[MG3D_R] : nullptr, ctx->partials,
+               ctx->sumsq + slot, ctx->stream);
+}
+
+extern "C" int mg3d_smooth(mg3d_ctx *ctx, int level, int post, int iters)
+{
+    CHK(check_field_level(ctx, 0, level, "mg3d_smooth"));
+    if (iters < 0)
+        return fail(MG3D_ERR_ARG, "mg3d_smooth: negative iteration count");
+    enqueue_smooth(ctx, level, post, iters);
+    return launch_ok("mg3d_smooth");
+}
+
+extern "C" int mg3d_residual(mg3d_ctx *ctx, int level, int store, double *norm)
+{
+    CHK(check_field_level(ctx, 0, level, "mg3d_residual"));
+    enqueue_residual(ctx, level, store, 0);
+    CHK(launch_ok("mg3d_residual"));
+    return read_norm(ctx, 0, norm);
+}
+
+extern "C" int mg3d_restrict(mg3d_ctx *ctx, int level)
+{
+    CHK(check_field_level(ctx, 0, level, "mg3d_restrict"));
+    if (level < 1)
+        return fail(MG3D_ERR_ARG, "mg3d_restrict: level 0 has no coarser level");
+    k_restrict(ctx->lv[level].g, ctx->lv[level].f[MG3D_R], ctx->lv[level - 1].g, ctx->lv[level - 1].f[MG3D_D],
+               ctx->stream);
+    return launch_ok("mg3d_restrict");
+}
+
+extern "C" int mg3d_prolong(mg3d_ctx *ctx, int level)
+{
+    CHK(check_field_level(ctx, 0, level, "mg3d_prolong"));
+    if (level < 1)
+        return fail(MG3D_ERR_ARG, "mg3d_prolong: level 0 has no coarser level");
+    k_prolong(ctx->lv[level - 1].g, ctx->lv[level - 1].f[MG3D_U], ctx->lv[level].g, ctx->lv[level].f[MG3D_U],
+              ctx->stream);
+    return launch_ok("mg3d_prolong");
+}
+
+extern "C" int mg3d_coarse_solve(mg3d_ctx *ctx)
+{
+    if (!ctx)
+        return fail(MG3D_ERR_ARG, "mg3d_coarse_solve: NULL context");
+    if (!ctx->have_lu)
+        return fail(MG3D_ERR_STATE, "mg3d_coarse_solve: no coarse LU set (mg3d_ctx_build_coarse / mg3d_ctx_set_lu)");
+    k_lu_solve(ctx->lu, ctx->lv[0].g, ctx->lv[0].f[MG3D_D], ctx->lv[0].f[MG3D_U], ctx->lu_work, ctx->stream);
+    return launch_ok("mg3d_coarse_solve");
+}
+
+extern "C" int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm)
+{
+    CHK(check_field_level(ctx, field, level, "mg3d_l2norm"));
+    k_sumsq(ctx->lv[level].g, ctx->lv[level].f[field], ctx->partials, ctx->sumsq, ctx->stream);
+    CHK(launch_ok("mg3d_l2norm"));
+    return read_norm(ctx, 0, norm);
+}
+
+/* ------------------------------------------------------------------ V-cycle */
+struct StageScope {
+    mg3d_ctx *ctx;
+    mg3d_ctx::Pending p;
+    bool on;
+    StageScope(mg3d_ctx *c, int l, int s) : ctx(c)
+    {
+        p.level = l;
+        p.stage = s;
+        p.a = p.b = nullptr;
+        on = ctx->timing == 1 || (ctx->timing == 2 && l == ctx->L - 1);
+        if (on && (p.a = take_event(ctx)))
+            (void)hipEventRecord(p.a, ctx->stream);
+    }
+    ~StageScope()
+    {
+        if (!on)
+            return;
+        if ((p.b = take_event(ctx)))
+            (void)hipEventRecord(p.b, ctx->stream);
+        ctx->pending.push_back(p);
+    }
+};
+
+/* vcycle, mg_3d.h:1242-1362, unrolled: descend q..1, solve level 0, ascend 1..q.
+ * The squared post-smoothing norm of level q goes to sumsq[slot]. */
+static int enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
+{
+    if (!ctx->have_lu)
+        return fail(MG3D_ERR_STATE, "mg3d_vcycle: no coarse LU set (mg3d_ctx_build_coarse / mg3d_ctx_set_lu)");
+    hipStream_t s = ctx->stream;
+    const int L = ctx->L;
+    for (int l = q; l >= 1; l--) {
+        Level &lev = ctx->lv[l];
+        if (l < L - 1)
+            (void)hipMemsetAsync(lev.f[MG3D_U], 0, lev.elems * sizeof(double), s); /* :1258-1259 */
+        {
+            StageScope t(ctx, l, MG3D_ST_SMOOTH1);
+            enqueue_smooth(ctx, l, 0, ctx->iters); /* :1282 */
+        }
+        {
+            StageScope t(ctx, l, MG3D_ST_RESIDUAL1);
+            enqueue_residual(ctx, l, 1, ctx->sumsq_slots - 1); /* :1294 (norm discarded) */
+        }
+        {
+            StageScope t(ctx, l, MG3D_ST_RESTRICT);
+            k_restrict(lev.g, lev.f[MG3D_R], ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_D], s); /* :1310 */
+        }
+    }
+    {
+        Level &l0 = ctx->lv[0];
+        if (0 < L - 1)
+            (void)hipMemsetAsync(l0.f[MG3D_U], 0, l0.elems * sizeof(double), s);
+        StageScope t(ctx, 0, MG3D_ST_RECURSE);
+        k_lu_solve(ctx->lu, l0.g, l0.f[MG3D_D], l0.f[MG3D_U], ctx->lu_work, s); /* :1270 */
+    }
+    for (int l = 1; l <= q; l++) {
+        Level &lev = ctx->lv[l];
+        {
+            StageScope t(ctx, l, MG3D_ST_PROLONG);
+            k_prolong(ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_U], lev.g, lev.f[MG3D_U], s); /* :1331 */
+        }
+        {
+            StageScope t(ctx, l, MG3D_ST_SMOOTH2);
+            enqueue_smooth(ctx, l, 1, ctx->iters); /* :1341 */
+        }
+        {
+            StageScope t(ctx, l, MG3D_ST_RESIDUAL2);
+            enqueue_residual(ctx, l, 0, l == q ? slot : ctx->sumsq_slots - 1); /* :1354 */
+        }
+    }
+    return launch_ok("mg3d_vcycle");
+}
+
+extern "C" int mg3d_vcycle(mg3d_ctx *ctx, int level, double *norm)
+{
+    CHK(check_field_level(ctx, 0, level, "mg3d_vcycle"));
+    if (level == 0) { /* q == 0: direct solve, returns 0 (mg_3d.h:1262-1277) */
+        CHK(mg3d_coarse_solve(ctx));
+        if (norm)
+            *norm = 0.;
+        return MG3D_OK;
+    }
+    CHK(enqueue_vcycle(ctx, level, 0));
+    return read_norm(ctx, 0, norm);
+}
+
+extern "C" int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms)
+{
+    if (!ctx || count < 0)
+        return fail(MG3D_ERR_ARG, "mg3d_vcycles: bad arguments");
+    const int q = ctx->L - 1;
+    if (q == 0) {
+        for (int c = 0; c < count; c++) {
+            CHK(mg3d_coarse_solve(ctx));
+            if (norms)
+                norms[c] = 0.;
+        }
+        return mg3d_sync(ctx);
+    }
+    const int batch = ctx->sumsq_slots - 1;
+    for (int done = 0; done < count;) {
+        const int nb = (count - done < batch) ? count - done : batch;
+        for (int c = 0; c < nb; c++)
+            CHK(enqueue_vcycle(ctx, q, c));
+        HIPCHK(hipMemcpyAsync(ctx->h_sumsq, ctx->sumsq, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        resolve_timers(ctx);
+        if (norms)
+            for (int c = 0; c < nb; c++)
+                norms[done + c] = sqrt(ctx->h_sumsq[c]);
+        done += nb;
+    }
+    return MG3D_OK;
+}
+
+/* ------------------------------------------------------------------- timing */
+extern "C" int mg3d_timing_enable(mg3d_ctx *ctx, int on)
+{
+    if (!ctx)
+        return fail(MG3D_ERR_ARG, "mg3d_timing_enable: NULL context");
+    ctx->timing = (on == 1 || on == 2) ? on : 0;
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_timing_reset(mg3d_ctx *ctx) /* resetTimingInfo, timing_info.h:34-38 */
+{
+    if (!ctx)
+        return fail(MG3D_ERR_ARG, "mg3d_timing_reset: NULL context");
+    if (!ctx->pending.empty()) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        resolve_timers(ctx);
+    }
+    for (auto &t : ctx->timers)
+        t = StageTimer{0, 0.};
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_timing_get(mg3d_ctx *ctx, int level, int stage, int *num_calls, double *seconds)
+{
+    if (!ctx || level < 0 || level >= ctx->L || stage < 0 || stage >= MG3D_NUM_STAGES)
+        return fail(MG3D_ERR_ARG, "mg3d_timing_get: bad level/stage");
+    if (!ctx->pending.empty()) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        resolve_timers(ctx);
+    }
+    const StageTimer &t = ctx->timers[(size_t)level * MG3D_NUM_STAGES + stage];
+    if (num_calls)
+        *num_calls = t.calls;
+    if (seconds)
+        *seconds = t.seconds;
+    return MG3D_OK;
+}
+
+/* ----------------------------------------------- host-pointer operator forms */
+struct ScratchCtx { /* a one- or two-level context for a single host-pointer call */
+    mg3d_ctx *ctx = nullptr;
+    ~ScratchCtx() { mg3d_ctx_destroy(ctx); }
+};
+
+static int scratch_create(const int *n, const double *h, int L, ScratchCtx &sc)
+{
+    CHK(ctx_create_sizes(n, h, L, 0, &sc.ctx));
+    sc.ctx->c = n[0];
+    sc.ctx->length = 0.;
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_host_smooth(double *v, const double *d, int N, double h, int iters, int post)
+{
+    if (!v || !d || N < 1 || iters < 0)
+        return fail(MG3D_ERR_ARG, "mg3d_host_smooth: bad arguments");
+    ScratchCtx sc;
+    CHK(scratch_create(&N, &h, 1, sc));
+    CHK(mg3d_upload(sc.ctx, MG3D_U, 0, v));
+    CHK(mg3d_upload(sc.ctx, MG3D_D, 0, d));
+    CHK(mg3d_smooth(sc.ctx, 0, post, iters));
+    return mg3d_download(sc.ctx, MG3D_U, 0, v);
+}
+
+extern "C" int mg3d_host_residual(const double *v, const double *d, int N, double h, double *res, double *norm)
+{
+    if (!v || !d || N < 1)
+        return fail(MG3D_ERR_ARG, "mg3d_host_residual: bad arguments");
+    ScratchCtx sc;
+    CHK(scratch_create(&N, &h, 1, sc));
+    CHK(mg3d_upload(sc.ctx, MG3D_U, 0, v));
+    CHK(mg3d_upload(sc.ctx, MG3D_D, 0, d));
+    if (res) /* only the interior of res is written (mg_3d.h:824-825): keep the caller's boundary values */
+        CHK(mg3d_upload(sc.ctx, MG3D_R, 0, res));
+    CHK(mg3d_residual(sc.ctx, 0, res != nullptr, norm));
+    if (res)
+        CHK(mg3d_download(sc.ctx, MG3D_R, 0, res));
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_host_restrict(const double *r, int Nf, double *dc, int Nc)
+{
+    if (!r || !dc || Nc < 1 || Nf != 2 * Nc - 1)
+        return fail(MG3D_ERR_ARG, "mg3d_host_restrict: need Nf == 2*Nc-1 (got %d, %d)", Nf, Nc);
+    const int n[2] = {Nc, Nf};
+    const double h[2] = {2., 1.};
+    ScratchCtx sc;
+    CHK(scratch_create(n, h, 2, sc));
+    CHK(mg3d_upload(sc.ctx, MG3D_R, 1, r));
+    CHK(mg3d_restrict(sc.ctx, 1));
+    return mg3d_download(sc.ctx, MG3D_D, 0, dc);
+}
+
+extern "C" int mg3d_host_prolong(const double *ec, int Nc, double *ef, int Nf)
+{
+    if (!ec || !ef || Nc < 1 || Nf != 2 * Nc - 1)
+        return fail(MG3D_ERR_ARG, "mg3d_host_prolong: need Nf == 2*Nc-1 (got %d, %d)", Nf, Nc);
+    const int n[2] = {Nc, Nf};
+    const double h[2] = {2., 1.};
+    ScratchCtx sc;
+    CHK(scratch_create(n, h, 2, sc));
+    CHK(mg3d_upload(sc.ctx, MG3D_U, 0, ec));
+    CHK(mg3d_upload(sc.ctx, MG3D_U, 1, ef));
+    CHK(mg3d_prolong(sc.ctx, 1));
+    return mg3d_download(sc.ctx, MG3D_U, 1, ef);
+}
+
+extern "C" int mg3d_host_lu_solve(const double *LU, int n, const double *b, double *x)
+{
+    if (!LU || !b || !x || n < 1)
+        return fail(MG3D_ERR_ARG, "mg3d_host_lu_solve: bad arguments");
+    /* treat the n-vector as an n x 1 x 1 "grid" so the padded-layout solve kernel applies */
+    CHK(require_device());
+    ScratchCtx sc;
+    mg3d_ctx *ctx = sc.ctx = ctx_new(1, 0);
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CHK(install_lu(ctx, LU, n, 4 * (size_t)n));
+    double *db = ctx->lu_work + 2 * (size_t)n, *dx = db + n;
+    HIPCHK(hipMemcpy(db, b, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    Geom g;
+    g.N = g.ni = n;
+    g.nj = g.nk = 1;
+    g.pitch = 1;
+    g.plane = 1;
+    g.ig0 = 0;
+    k_lu_solve(ctx->lu, g, db, dx, ctx->lu_work, ctx->stream);
+    CHK(launch_ok("mg3d_host_lu_solve"));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(x, dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_host_vcycle(double **u, double **f, double **res, double h, int q, int num_levels, int iters,
+                                int N, const double *LU, double *norm)
+{
+    if (!u || !f || !res || !LU || q < 0 || q >= num_levels || N < 3 || iters < 0)
+        return fail(MG3D_ERR_ARG, "mg3d_host_vcycle: bad arguments");
+    /* level sizes below q: N_coarse = (N+1)/2 (mg_3d.h:1302), h_coarse = 2h (mg_3d.h:1303) */
+    std::vector<int> n(q + 1);
+    std::vector<double> hh(q + 1);
+    n[q] = N;
+    hh[q] = h;
+    for (int l = q - 1; l >= 0; l--) {
+        if (n[l + 1] < 3 || (n[l + 1] & 1) == 0)
+            return fail(MG3D_ERR_ARG, "mg3d_host_vcycle: level %d has %d points per side, cannot coarsen", l + 1,
+                        n[l + 1]);
+        n[l] = (n[l + 1] + 1) / 2;
+        hh[l] = 2 * hh[l + 1];
+    }
+    ScratchCtx sc;
+    CHK(scratch_create(n.data(), hh.data(), q + 1, sc));
+    mg3d_ctx *ctx = sc.ctx;
+    /* the memset of mg_3d.h:1258 is skipped only on the caller's finest level (q == numLevels-1):
+     * emulate by telling the context how many levels the caller's hierarchy has */
+    ctx->iters = iters;
+    CHK(mg3d_ctx_set_lu(ctx, LU));
+    CHK(mg3d_upload(ctx, MG3D_U, q, u[q]));
+    CHK(mg3d_upload(ctx, MG3D_D, q, f[q]));
+    /* r is written on interiors only: start from the caller's arrays so untouched entries survive */
+    for (int l = 1; l <= q; l++)
+        CHK(mg3d_upload(ctx, MG3D_R, l, res[l]));
+    if (q == 0) {
+        CHK(mg3d_coarse_solve(ctx));
+        if (norm)
+            *norm = 0.;
+        return mg3d_download(ctx, MG3D_U, 0, u[0]);
+    }
+    if (q < num_levels - 1) /* not the caller's finest level: its guess is zeroed first (:1258) */
+        CHK(mg3d_zero(ctx, MG3D_U, q));
+    CHK(enqueue_vcycle(ctx, q, 0));
+    CHK(read_norm(ctx, 0, norm));
+    for (int l = 0; l <= q; l++) {
+        CHK(mg3d_download(ctx, MG3D_U, l, u[l]));
+        if (l < q)
+            CHK(mg3d_download(ctx, MG3D_D, l, f[l]));
+        if (l >= 1)
+            CHK(mg3d_download(ctx, MG3D_R, l, res[l]));
+    }
+    return MG3D_OK;
+}

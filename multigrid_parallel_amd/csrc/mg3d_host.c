@@ -1,0 +1,167 @@
+/*
+ * mg3d_host.c -- host-only pieces of libmg3d.so: problem set-up, coarse
+ * operator assembly + factorisation (done once per solver, mg_3d.h:282-289),
+ * VTK output.  None of this is on the V-cycle hot path; the hot path is HIP
+ * (mg3d_kernels.hip).  Compiled with -ffp-contract=off so that results are
+ * bit-identical to the reference built by gcc -O2.
+ */
+#include "mg3d.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+/* BCFunc, mg_3d.h:89-90 */
+double mg3d_bc_func(double x, double y, double z) { return x * x - 2 * y * y + z * z; }
+
+/* setupBoundaryConditions, mg_3d.h:1147-1239: Dirichlet value BCFunc(i*h, j*h, k*h)
+ * on every point that lies on one of the six faces. */
+void mg3d_fill_boundary_host(double *v, int N, double h)
+{
+    const long NN = (long)N * N;
+    for (int i = 0; i < N; i++) {
+        const double x = i * h;
+        for (int j = 0; j < N; j++) {
+            const double y = j * h;
+            double *row = v + NN * i + (long)N * j;
+            if (i == 0 || i == N - 1 || j == 0 || j == N - 1) {
+                for (int k = 0; k < N; k++)
+                    row[k] = mg3d_bc_func(x, y, k * h);
+            } else {
+                row[0] = mg3d_bc_func(x, y, 0 * h);
+                row[N - 1] = mg3d_bc_func(x, y, (N - 1) * h);
+            }
+        }
+    }
+}
+
+/* constructCoarseMatrixA, mg_3d.h:147-273.  Row `p` of the dense n x n matrix:
+ * identity on boundary nodes (:179-185), (1,1,1,1,1,1,-6)/h^2 on interior
+ * nodes (:257-268).  A must be zero on entry (calloc, mg_3d.h:283). */
+void mg3d_coarse_matrix(double *A, int N, double h)
+{
+    const long NN = (long)N * N, n = NN * N;
+    const double hSq = h * h;
+    const double invHsq = 1. / hSq;
+    const double off = 1. * invHsq, diag = 6. * invHsq;
+    long p = 0;
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++)
+            for (int k = 0; k < N; k++, p++) {
+                double *row = A + p * n;
+                const int interior = i > 0 && i < N - 1 && j > 0 && j < N - 1 && k > 0 && k < N - 1;
+                if (!interior) {
+                    row[p] = 1.;
+                    continue;
+                }
+                row[p - NN] = off;
+                row[p + NN] = off;
+                row[p - N] = off;
+                row[p + N] = off;
+                row[p - 1] = off;
+                row[p + 1] = off;
+                row[p] = -diag;
+            }
+}
+
+/* convertToLU_InPlace, gauss_elim.h:9-29: Doolittle, unit-lower, no pivoting,
+ * row-major in place.  The multiplier z = a[k][i] / a[i][i] is formed as
+ * a[k][i] * (1/a[i][i]) exactly as :17,:22 do.  Rows whose multiplier is an
+ * exact zero are skipped (a -= 0*x leaves a unchanged), as are columns past the
+ * last non-zero of the pivot row: the matrix is banded (half-width N^2), which
+ * turns the O(n^3) dense sweep into O(n * bw^2). */
+void mg3d_lu_factor(double *a, int n)
+{
+    for (int i = 0; i < n - 1; i++) {
+        const double *ri = a + (long)n * i;
+        const double pinv = 1. / ri[i];
+        int last = n - 1; /* last non-zero column of the pivot row */
+        while (last > i && ri[last] == 0.)
+            last--;
+        for (int k = i + 1; k < n; k++) {
+            double *rk = a + (long)n * k;
+            if (rk[i] == 0.) {
+                rk[i] = rk[i] * pinv; /* keeps the sign of zero the reference would store */
+                continue;
+            }
+            const double z = rk[i] * pinv;
+            rk[i] = z;
+            for (int j = i + 1; j <= last; j++)
+                rk[j] -= z * ri[j];
+        }
+    }
+}
+
+/* GetL2NormOfVector, mg_3d.h:783-792 (sequential sum, all n entries) */
+double mg3d_l2norm_host(const double *d, long n)
+{
+    double s = 0.;
+    for (long i = 0; i < n; i++)
+        s += d[i] * d[i];
+    return sqrt(s);
+}
+
+/* updateEdgeValues, mg_3d.h:304-430: cosmetic averaging of the 12 edges
+ * (0.5 * the two face neighbours) and then the 8 corners ((1./3) * the three
+ * edge neighbours).  The stencil never reads these points. */
+void mg3d_smooth_edges_host(double *u, int N)
+{
+    const long sI = (long)N * N, sJ = N, sK = 1;
+    const long stride[3] = {sI, sJ, sK};
+    /* An edge runs along axis `a`; the two other axes (b, c) sit at 0 or N-1.
+     * Neighbour order inside the sum follows the reference: for edges along j
+     * the k-neighbour comes first (:316), along k the j-neighbour (:330), along
+     * i the j-neighbour (:372).  a+b is commutative, so only membership matters. */
+    for (int a = 0; a < 3; a++) {
+        const int b = (a + 1) % 3, c = (a + 2) % 3;
+        for (int eb = 0; eb < 2; eb++)
+            for (int ec = 0; ec < 2; ec++) {
+                const long base = (eb ? (N - 1) * stride[b] : 0) + (ec ? (N - 1) * stride[c] : 0);
+                const long nb = eb ? -stride[b] : stride[b], nc = ec ? -stride[c] : stride[c];
+                for (int t = 1; t < N - 1; t++) {
+                    const long p = base + t * stride[a];
+                    u[p] = 0.5 * (u[p + nb] + u[p + nc]);
+                }
+            }
+    }
+    /* corners (:394-429): (1./3) * (k-neighbour + j-neighbour + i-neighbour), in that order */
+    for (int ci = 0; ci < 2; ci++)
+        for (int cj = 0; cj < 2; cj++)
+            for (int ck = 0; ck < 2; ck++) {
+                const long p = (ci ? (N - 1) * sI : 0) + (cj ? (N - 1) * sJ : 0) + (ck ? (N - 1) * sK : 0);
+                const long di = ci ? -sI : sI, dj = cj ? -sJ : sJ, dk = ck ? -sK : sK;
+                u[p] = (1. / 3) * (u[p + dk] + u[p + dj] + u[p + di]);
+            }
+}
+
+/* writeOutputData, postprocess.h:5-47: ASCII legacy-VTK structured grid,
+ * coordinates then one scalar per point, "%10.8e". */
+int mg3d_write_vtk(const char *file_name, const double *grid, double h, int N)
+{
+    FILE *f = fopen(file_name, "w");
+    if (!f)
+        return MG3D_ERR_ARG;
+    const long total = (long)N * N * N;
+    fprintf(f,
+            "# vtk DataFile Version 2.0\n"
+            "Potential data\n"
+            "ASCII\n"
+            "DATASET STRUCTURED_GRID\n"
+            "DIMENSIONS %d %d %d\n"
+            "POINTS %ld float\n",
+            N, N, N, total);
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++)
+            for (int k = 0; k < N; k++)
+                fprintf(f, "%10.8e %10.8e %10.8e\n", h * i, h * j, h * k);
+    fprintf(f,
+            "\n"
+            "POINT_DATA %ld\n"
+            "SCALARS data float 1\n"
+            "LOOKUP_TABLE default\n",
+            total);
+    for (long p = 0; p < total; p++)
+        fprintf(f, "%10.8e\n", grid[p]);
+    fclose(f);
+    return MG3D_OK;
+}

@@ -1,0 +1,46 @@
+/* mg3d_internal.h -- shared between mg3d_ctx.hip and mg3d_kernels.hip (not installed). */
+#ifndef MG3D_INTERNAL_H
+#define MG3D_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#include "mg3d.h"
+
+/* Geometry of one (local) level as the kernels see it.
+ * Device layout: idx = plane*i + pitch*j + k, pitch % 16 == 0 (128-byte rows),
+ * plane = pitch*nj.  A single-GPU level has ni = nj = nk = N and ig0 = 0; an
+ * i-slab of a distributed level has ni = owned planes + 2 (halo or physical
+ * boundary on either side) and ig0 = global index of its local plane 0. */
+struct Geom {
+    int ni, nj, nk;
+    int pitch;
+    long long plane;
+    int ig0; /* global i of local plane 0 (colour parity, grid-transfer alignment) */
+    int N;   /* global points per side */
+};
+
+static inline int mg3d_pitch_for(int nk) { return (nk + 15) & ~15; }
+
+struct LuBand {
+    int n;        /* unknowns */
+    int bw;       /* half bandwidth actually populated (max |i-j| with LU[i][j] != 0) */
+    double *lcol; /* [n][bw]  lcol[j*bw+t] = LU[j+1+t][j]   (strictly lower, by column) */
+    double *ucol; /* [n][bw]  ucol[j*bw+t] = LU[j-1-t][j]   (strictly upper, by column) */
+    double *diag; /* [n] */
+};
+
+#define MG3D_MAX_PARTIALS 8192
+
+/* launchers (mg3d_kernels.hip); all asynchronous on `s` */
+void k_smooth_color(const Geom &g, double *v, const double *d, double hSq, int color, hipStream_t s);
+/* writes partials (one per block) then reduces them, in a fixed order, into *sumsq_out */
+void k_residual(const Geom &g, const double *v, const double *d, double invHsq, double *res, double *partials,
+                double *sumsq_out, hipStream_t s);
+void k_sumsq(const Geom &g, const double *a, double *partials, double *sumsq_out, hipStream_t s);
+void k_restrict(const Geom &gf, const double *r, const Geom &gc, double *dc, hipStream_t s);
+void k_prolong(const Geom &gc, const double *ec, const Geom &gf, double *ef, hipStream_t s);
+/* b and x are level-0 grids in the padded layout g0; work holds 2n doubles */
+void k_lu_solve(const LuBand &lu, const Geom &g0, const double *b_pad, double *x_pad, double *work, hipStream_t s);
+
+#endif

@@ -1,0 +1,116 @@
+"""CPU-side checks of the drop-in boundary: libmg3d.so loads, exports every symbol include/mg3d.h declares,
+the ctypes table covers the same set, host-only helpers match the oracle, and compute entry points fail
+loudly (MG3D_ERR_NO_DEVICE) instead of falling back when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import multigrid_parallel_amd as M
+from multigrid_parallel_amd.binding import SIGNATURES, P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "mg3d.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mg3d_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    L = C.CDLL(M.lib_path())
+    names = declared_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/mg3d.h but not exported"
+    assert sorted(SIGNATURES) == names
+
+
+def test_no_oracle_in_product():
+    """The product must not link, load or reference anything under oracle/."""
+    import subprocess
+    out = subprocess.run(["ldd", M.lib_path()], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    for root, _, files in os.walk(os.path.join(ROOT, "multigrid_parallel_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".c", ".h", "Makefile")):
+                assert "oracle" not in open(os.path.join(root, f)).read().lower(), f
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().lower(), f
+
+
+def test_host_helpers_match_oracle():
+    L = M.lib()
+    for N in (3, 5, 9):
+        h = 1.0 / (N - 1) / 3.0
+        rng = np.random.default_rng(N)
+        a = rng.uniform(-1, 1, N ** 3)
+        b = a.copy()
+        L.mg3d_fill_boundary_host(P(a), N, h)
+        O.lib().orc_fill_boundary(O.P(b), N, h)
+        assert np.array_equal(a, b)
+        assert L.mg3d_l2norm_host(P(a), N ** 3) == O.lib().orc_l2norm(O.P(a), N ** 3)
+    assert L.mg3d_bc_func(0.3, 0.7, 0.9) == O.lib().orc_bc_func(0.3, 0.7, 0.9)
+    for N in (3, 5):
+        n = N ** 3
+        A, B = np.zeros(n * n), np.zeros(n * n)
+        L.mg3d_coarse_matrix(P(A), N, 0.37)
+        O.lib().orc_coarse_matrix(O.P(B), N, 0.37)
+        assert np.array_equal(A, B)
+        L.mg3d_lu_factor(P(A), n)
+        O.lib().orc_lu_factor(O.P(B), n)
+        assert np.array_equal(A, B)
+
+
+def test_lu_factor_band_skip_equals_dense_sweep_c9():
+    n = 729
+    A, B = np.zeros(n * n), np.zeros(n * n)
+    M.lib().mg3d_coarse_matrix(P(A), 9, 0.125)
+    O.lib().orc_coarse_matrix(O.P(B), 9, 0.125)
+    M.lib().mg3d_lu_factor(P(A), n)
+    O.lib().orc_lu_factor(O.P(B), n)
+    assert np.array_equal(A, B)
+
+
+def test_vtk_writer_format(tmp_path):
+    N, h = 3, 0.5
+    g = np.arange(27, dtype=np.float64) / 7
+    p = tmp_path / "o.vtk"
+    assert M.lib().mg3d_write_vtk(str(p).encode(), P(g), h, N) == 0
+    lines = p.read_text().split("\n")
+    assert lines[:6] == ["# vtk DataFile Version 2.0", "Potential data", "ASCII", "DATASET STRUCTURED_GRID",
+                         "DIMENSIONS 3 3 3", "POINTS 27 float"]
+    assert lines[6] == "0.00000000e+00 0.00000000e+00 0.00000000e+00"
+    assert lines[7] == "0.00000000e+00 0.00000000e+00 5.00000000e-01"
+    assert lines[6 + 27] == "" and lines[6 + 28] == "POINT_DATA 27"
+    assert lines[6 + 31] == "0.00000000e+00" and lines[6 + 32] == "%10.8e" % (1 / 7)
+
+
+def test_edge_smoothing_matches_reference_formulas():
+    N = 5
+    u = np.random.default_rng(3).uniform(-1, 1, (N, N, N))
+    w = u.copy().reshape(-1)
+    M.lib().mg3d_smooth_edges_host(P(w), N)
+    w = w.reshape(N, N, N)
+    # an edge along j at i=0,k=0 (mg_3d.h:312-317) and the (0,0,0) corner (mg_3d.h:397-399)
+    for j in range(1, N - 1):
+        assert w[0, j, 0] == 0.5 * (u[0, j, 1] + u[1, j, 0])
+    assert w[0, 0, 0] == (1. / 3) * (w[0, 0, 1] + w[0, 1, 0] + w[1, 0, 0])
+    assert np.array_equal(w[1:-1, 1:-1, :], u[1:-1, 1:-1, :])
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
+def test_compute_fails_loudly_without_gpu():
+    L = M.lib()
+    assert L.mg3d_device_count() == 0
+    h = C.c_void_p()
+    assert L.mg3d_ctx_create(5, 3, 2, 1.0, C.byref(h)) == 2  # MG3D_ERR_NO_DEVICE
+    assert b"no CPU fallback" in L.mg3d_last_error()
+    a = np.zeros(27)
+    assert L.mg3d_host_smooth(P(a), P(a), 3, 0.5, 1, 0) == 2
+    with pytest.raises(M.Mg3dError):
+        M.Solver(5, 3, 2)
