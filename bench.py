@@ -36,11 +36,24 @@ def algorithmic_bytes_per_cycle(c, L, nu, w=8):
     return tot + (n0 * n0 + 2 * n0) * w
 
 
+def host_cores():
+    """Host cores this job may use: affinity, capped by the cgroup CPU quota and by the GPU box's per-GPU
+    CPU share (16; MG3D_CPU_THREADS overrides)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("MG3D_CPU_THREADS", "16"))))
+
+
 def cpu_child(args):
     """Runs in a fresh process so OMP_NUM_THREADS is honoured and no GPU runtime is loaded."""
     import ctypes as C
     import numpy as np
-    cores = len(os.sched_getaffinity(0))
+    cores = int(os.environ["OMP_NUM_THREADS"])
     ref = os.path.join(ROOT, "oracle", "_ref", "libmg3d_ref.so")
     port = os.path.join(ROOT, "oracle", "liboracle.so")
     dp = C.POINTER(C.c_double)
@@ -67,14 +80,14 @@ def cpu_child(args):
     per = secs / (cycles + 1)
     print(json.dumps({"value": 1.0 / per, "unit": "V-cycles/s", "cores": cores, "kind": kind,
                       "sample": f"{cycles + 1} consecutive V({args.nu},{args.nu}) cycles of the same {N}^3 problem "
-                                f"(args {args.coarse} {args.levels} {args.nu}), OpenMP over all {cores} host cores, "
+                                f"(args {args.coarse} {args.levels} {args.nu}), OpenMP on {cores} host cores (this GPU's CPU share), "
                                 f"omp_get_wtime around the cycle loop as test_mg_3d.c:36,68",
                       "seconds_per_cycle": per, "last_norm": float(norms[cycles])}))
 
 
 def run_cpu_baseline(args):
     env = dict(os.environ)
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     env.update(OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores")
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", "--coarse", str(args.coarse), "--levels",
            str(args.levels), "--nu", str(args.nu), "--cpu-cycles", str(args.cpu_cycles)]

@@ -113,9 +113,11 @@ int mg3d_host_restrict(const double *r, int Nf, double *dc, int Nc);
 int mg3d_host_prolong(const double *ec, int Nc, double *ef, int Nf);
 int mg3d_host_lu_solve(const double *LU, int n, const double *b, double *x);
 /* vcycle(u,f,res,h,q,numLevels,smootherIter,N,LU), mg_3d.h:1242: caller-owned
- * host hierarchies (allocGridLevels).  Levels 0..q are copied back after the cycle. */
+ * host hierarchies (allocGridLevels).  Levels 0..q are copied back after the cycle.
+ * stage_calls / stage_seconds (optional, (q+1)*MG3D_NUM_STAGES entries, [level][stage])
+ * are incremented by this cycle's per-stage event timings (tInfo of mg_3d.h:1279-1359). */
 int mg3d_host_vcycle(double **u, double **f, double **res, double h, int q, int num_levels, int iters, int N,
-                     const double *LU, double *norm);
+                     const double *LU, double *norm, int *stage_calls, double *stage_seconds);
 
 /* --------------------------------------------------- host-only helpers (no device)
  * mg3d_bc_func            : BCFunc (mg_3d.h:89-90)

@@ -62,7 +62,7 @@ SIGNATURES = {
     "mg3d_host_prolong": (C.c_int, [dp, C.c_int, dp, C.c_int]),
     "mg3d_host_lu_solve": (C.c_int, [dp, C.c_int, dp, dp]),
     "mg3d_host_vcycle": (C.c_int, [C.POINTER(dp), C.POINTER(dp), C.POINTER(dp), C.c_double, C.c_int, C.c_int, C.c_int,
-                                   C.c_int, dp, dp]),
+                                   C.c_int, dp, dp, C.POINTER(C.c_int), dp]),
     "mg3d_bc_func": (C.c_double, [C.c_double, C.c_double, C.c_double]),
     "mg3d_fill_boundary_host": (None, [dp, C.c_int, C.c_double]),
     "mg3d_coarse_matrix": (None, [dp, C.c_int, C.c_double]),

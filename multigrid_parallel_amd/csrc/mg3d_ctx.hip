@@ -764,7 +764,7 @@ extern "C" int mg3d_host_lu_solve(const double *LU, int n, const double *b, doub
 }
 
 extern "C" int mg3d_host_vcycle(double **u, double **f, double **res, double h, int q, int num_levels, int iters,
-                                int N, const double *LU, double *norm)
+                                int N, const double *LU, double *norm, int *stage_calls, double *stage_seconds)
 {
     if (!u || !f || !res || !LU || q < 0 || q >= num_levels || N < 3 || iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_host_vcycle: bad arguments");
@@ -786,6 +786,7 @@ extern "C" int mg3d_host_vcycle(double **u, double **f, double **res, double h, 
     /* the memset of mg_3d.h:1258 is skipped only on the caller's finest level (q == numLevels-1):
      * emulate by telling the context how many levels the caller's hierarchy has */
     ctx->iters = iters;
+    ctx->timing = (stage_calls || stage_seconds) ? 1 : 0;
     CHK(mg3d_ctx_set_lu(ctx, LU));
     CHK(mg3d_upload(ctx, MG3D_U, q, u[q]));
     CHK(mg3d_upload(ctx, MG3D_D, q, f[q]));
@@ -793,15 +794,32 @@ extern "C" int mg3d_host_vcycle(double **u, double **f, double **res, double h, 
     for (int l = 1; l <= q; l++)
         CHK(mg3d_upload(ctx, MG3D_R, l, res[l]));
     if (q == 0) {
-        CHK(mg3d_coarse_solve(ctx));
+        {
+            StageScope t(ctx, 0, MG3D_ST_RECURSE);
+            CHK(mg3d_coarse_solve(ctx));
+        }
         if (norm)
             *norm = 0.;
-        return mg3d_download(ctx, MG3D_U, 0, u[0]);
+        CHK(mg3d_download(ctx, MG3D_U, 0, u[0]));
+        if (stage_calls)
+            stage_calls[MG3D_ST_RECURSE] += ctx->timers[MG3D_ST_RECURSE].calls;
+        if (stage_seconds)
+            stage_seconds[MG3D_ST_RECURSE] += ctx->timers[MG3D_ST_RECURSE].seconds;
+        return MG3D_OK;
     }
     if (q < num_levels - 1) /* not the caller's finest level: its guess is zeroed first (:1258) */
         CHK(mg3d_zero(ctx, MG3D_U, q));
     CHK(enqueue_vcycle(ctx, q, 0));
-    CHK(read_norm(ctx, 0, norm));
+    double nrm = 0.;
+    CHK(read_norm(ctx, 0, &nrm)); /* synchronises and resolves the stage timers */
+    if (norm)
+        *norm = nrm;
+    for (size_t t = 0; t < ctx->timers.size(); t++) {
+        if (stage_calls)
+            stage_calls[t] += ctx->timers[t].calls;
+        if (stage_seconds)
+            stage_seconds[t] += ctx->timers[t].seconds;
+    }
     for (int l = 0; l <= q; l++) {
         CHK(mg3d_download(ctx, MG3D_U, l, u[l]));
         if (l < q)

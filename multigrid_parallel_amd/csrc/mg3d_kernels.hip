@@ -327,9 +327,18 @@ __device__ __forceinline__ void lu_wave_load(const LuBand &lu, int j, int lane, 
     }
 }
 
-/* One substitution pass.  rhs/out/dg are dense LDS vectors; the factor's columns
- * are fetched U steps ahead (they do not depend on the solution), so the
- * dependency chain per step is: sum -> subtract (-> divide) -> readlane -> multiply -> add. */
+__device__ __forceinline__ double readlane_f64(double x, int lane_uniform)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane_uniform);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane_uniform);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+/* One substitution pass.  rhs/out/dg are dense LDS vectors.  Everything that does not
+ * depend on the solution -- the factor's columns, rhs[j], the diagonal -- is fetched a
+ * chunk (U steps) ahead, and x[j] travels by v_readlane, so the dependency chain per
+ * step is: subtract (-> divide) -> readlane -> multiply -> add. */
 template <int R, bool FWD>
 __device__ __forceinline__ void lu_wave_pass(const LuBand &lu, int lane, const double *rhs, double *out,
                                              const double *dg)
@@ -340,17 +349,23 @@ __device__ __forceinline__ void lu_wave_pass(const LuBand &lu, int lane, const d
 #pragma unroll
     for (int r = 0; r < R; r++)
         S[r] = 0.;
-    double nxt[U][R], cur[U][R];
+    double nxt[U][R], cur[U][R], rj[U], dj[U];
     const int nch = (n + U - 1) / U;
 #pragma unroll
     for (int u = 0; u < U; u++)
         lu_wave_load<R, FWD>(lu, FWD ? u : n - 1 - u, lane, nxt[u]);
     for (int c = 0; c < nch; c++) {
 #pragma unroll
-        for (int u = 0; u < U; u++)
+        for (int u = 0; u < U; u++) {
 #pragma unroll
             for (int q = 0; q < R; q++)
                 cur[u][q] = nxt[u][q];
+            const int step = c * U + u;
+            const int j = FWD ? step : n - 1 - step;
+            const bool in = step < n;
+            rj[u] = in ? rhs[j] : 0.; /* uniform address: LDS broadcast */
+            dj[u] = (!FWD && in) ? dg[j] : 1.;
+        }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int jn = (c + 1) * U + u;
@@ -363,36 +378,31 @@ __device__ __forceinline__ void lu_wave_pass(const LuBand &lu, int lane, const d
                 break;
             const int j = FWD ? step : n - 1 - step;
             const int owner = j & 63, slot = (j >> 6) % R;
-            double mine = 0.;
+            double mine = S[0];
 #pragma unroll
-            for (int r = 0; r < R; r++)
-                if (r == slot)
-                    mine = S[r];
-            double xj = 0.;
-            if (lane == owner) {
-                xj = rhs[j] - mine;
-                if (!FWD)
-                    xj = xj / dg[j];
+            for (int r = 1; r < R; r++)
+                mine = (r == slot) ? S[r] : mine;
+            double cand = rj[u] - mine;
+            if (!FWD)
+                cand = cand / dj[u];
+            const double xj = readlane_f64(cand, owner);
+            const bool own = lane == owner;
+            if (own)
                 out[j] = xj;
-            }
-            xj = __shfl(xj, owner, WAVE);
 #pragma unroll
             for (int r = 0; r < R; r++)
-                if (r == slot && lane == owner)
-                    S[r] = 0.; /* the slot now belongs to the row 64*R further on */
+                S[r] = (own && r == slot) ? 0. : S[r]; /* the slot now belongs to the row 64*R further on */
             const int t0 = FWD ? ((lane - j - 1) & 63) : ((j - 1 - lane) & 63);
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 const int t = t0 + 64 * q;
                 const int i = FWD ? j + 1 + t : j - 1 - t;
-                if (t < lu.bw && i >= 0 && i < n) {
-                    const double prod = cur[u][q] * xj;
-                    const int sl = (i >> 6) % R;
+                const bool ok = t < lu.bw && i >= 0 && i < n;
+                const double prod = cur[u][q] * xj;
+                const int sl = (i >> 6) % R;
 #pragma unroll
-                    for (int r = 0; r < R; r++)
-                        if (r == sl)
-                            S[r] += prod;
-                }
+                for (int r = 0; r < R; r++)
+                    S[r] = (ok && r == sl) ? S[r] + prod : S[r];
             }
         }
     }

@@ -1,0 +1,154 @@
+"""The drop-in boundary: the reference's own drivers, unchanged, against include/mg_3d.h + libmg3d.so.
+
+CPU (here): oracle/Makefile compiles /root/reference/test_mg_3d.c and test_mg_3d_dirichlet.c untouched
+against the repo's headers (link gate), and without a GPU they fail loudly rather than falling back.
+GPU box: the binaries built here travel in oracle/_ref/ and are run; their printed residual histories
+must equal the reference's known answers."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+ROOT = O.ROOT
+REF = "/root/reference"
+BIN1 = os.path.join(ROOT, "oracle", "_ref", "dropin_test_mg_3d")
+BIN2 = os.path.join(ROOT, "oracle", "_ref", "dropin_test_mg_3d_dirichlet")
+HAVE_GPU = os.path.exists("/dev/kfd")
+
+
+def run(cmd, cwd, threads=None):
+    env = dict(os.environ)
+    if threads:
+        env["OMP_NUM_THREADS"] = str(threads)
+    return subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference tree only exists in the build container")
+def test_reference_drivers_compile_and_link_unchanged(tmp_path):
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "dropin"], check=True, capture_output=True)
+    assert os.path.exists(BIN1) and os.path.exists(BIN2)
+    out = subprocess.run(["ldd", BIN1], capture_output=True, text=True).stdout
+    assert "libmg3d.so" in out and "multigrid_parallel_amd/lib" in out
+    # argument handling is the reference's: usage + exit 1 (mg_3d.h:109-113), abort on non-pow2 (:123)
+    r = run([BIN1], tmp_path)
+    assert r.returncode == 1 and r.stdout.startswith("Usage:")
+    r = run([BIN1, "4", "3", "2"], tmp_path)
+    assert r.returncode == -6 or r.returncode == 134
+    r = run([BIN2], tmp_path)
+    assert r.returncode == 1 and r.stdout.startswith("Usage:")
+
+
+@pytest.mark.skipif(HAVE_GPU or not os.path.exists(BIN1), reason="needs the CPU-only container")
+def test_drivers_fail_loudly_without_gpu(tmp_path):
+    for b in (BIN1, BIN2):
+        r = run([b, "5", "3", "2"], tmp_path)
+        assert r.returncode == 1
+        assert "no CPU fallback" in r.stderr
+
+
+def history(stdout):
+    return [float(m) for m in re.findall(r"Residual Norm:\s*(\S+)", stdout)]
+
+
+KNOWN_5_5_2 = [74651.9, 9198.35, 1219.39, 170.177, 24.6618, 3.68103, 0.563252, 0.0880884, 0.0140466, 0.00227868,
+               0.000375223, 6.25855e-05, 1.05534e-05, 1.79591e-06, 3.0789e-07]
+KNOWN_DIR_5_5_2 = [74831.4, 9392.75, 1372.13, 265.208, 69.895, 21.3226, 6.76706, 2.16709, 0.695417, 0.223269]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [1, 4])
+def test_reference_test_mg_3d_runs_on_gpu(tmp_path, threads):
+    if not os.path.exists(BIN1):
+        pytest.skip("oracle/_ref/dropin_test_mg_3d was not built (no reference tree at build time)")
+    r = run([BIN1, "5", "5", "2"], tmp_path, threads)
+    assert r.returncode == 0, r.stderr
+    assert history(r.stdout) == pytest.approx(KNOWN_5_5_2, rel=2e-6)  # 6 printed digits
+    assert f"Max threads: {threads}" in r.stdout
+    err = float(re.search(r"Error norm:\s*(\S+)", r.stdout).group(1))
+    assert err == pytest.approx(1.60434e-09, rel=1e-5)
+    assert "LEVEL 4" in r.stdout and re.search(r"Smoother1\s+15\s", r.stdout)
+    assert os.path.getsize(tmp_path / "diff2.vtk") > 65 ** 3 * 10
+
+
+@pytest.mark.gpu
+def test_reference_test_mg_3d_dirichlet_runs_on_gpu(tmp_path):
+    if not os.path.exists(BIN2):
+        pytest.skip("oracle/_ref/dropin_test_mg_3d_dirichlet was not built")
+    r = run([BIN2, "5", "5", "2"], tmp_path, 1)
+    assert r.returncode == 0, r.stderr
+    assert history(r.stdout) == pytest.approx(KNOWN_DIR_5_5_2, rel=2e-6)
+    assert "Error norm: 0.000000" in r.stdout  # the driver's `errNorm = diff*diff` overwrite (:90)
+    assert re.search(r"CalcResidual2\s+10\s", r.stdout)
+
+
+@pytest.mark.gpu
+def test_api_surface_driver(tmp_path):
+    """tests/c/api_surface.c (ours) compiled on the box against include/, compared with the oracle."""
+    exe = tmp_path / "api_surface"
+    subprocess.run(["gcc", "-O2", "-fopenmp", "-I" + os.path.join(ROOT, "include"), "-o", str(exe),
+                    os.path.join(ROOT, "tests", "c", "api_surface.c"), "-L" + os.path.join(ROOT, "multigrid_parallel_amd", "lib"),
+                    "-Wl,-rpath," + os.path.join(ROOT, "multigrid_parallel_amd", "lib"), "-lmg3d", "-lm"], check=True)
+    r = run([str(exe)], tmp_path, 2)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    val = lambda tag: [[float(x) for x in m.split()] for m in re.findall(rf"^{tag} (.*)$", out, flags=re.M)]
+
+    # replay the same sequence with the oracle
+    lib = O.lib()
+    lib.orc_set_threads(1)
+    st = [12345.0]
+
+    def rnd():
+        st[0] = (st[0] * 16807.0) % 2147483647.0
+        return 2.0 * (st[0] / 2147483647.0) - 1.0
+
+    N, Nc = 9, 5
+    h = 1.0 / (N - 1)
+    v, f = np.zeros(N ** 3), np.zeros(N ** 3)
+    for p in range(N ** 3):
+        v[p] = rnd()
+        f[p] = rnd()
+    res, dc = np.zeros(N ** 3), np.zeros(Nc ** 3)
+    lib.orc_pre_smooth(O.P(v), O.P(f), N, h, 2)
+    lib.orc_post_smooth(O.P(v), O.P(f), N, h, 1)
+    nrm = lib.orc_residual(O.P(v), O.P(f), N, h, O.P(res))
+    lib.orc_restrict(O.P(res), N, O.P(dc), Nc)
+    lib.orc_prolong(O.P(dc), Nc, O.P(v), N)
+    sv = 0.0
+    for p in range(N ** 3):
+        sv += v[p] * (1 + p % 7)
+    sd = 0.0
+    for p in range(Nc ** 3):
+        sd += dc[p] * (1 + p % 5)
+    got = val("OPS")[0]
+    assert got[0] == pytest.approx(nrm, rel=1e-13)
+    assert got[1] == sv and got[2] == sd and got[3] == lib.orc_l2norm(O.P(f), N ** 3)
+
+    # 9-argument vcycle on caller-owned hierarchies, correct coarse spacing
+    c, L, nu = 3, 3, 2
+    H = O.Hierarchy(c, L)
+    Nf, hf = H.N[-1], 1.0 / (H.N[-1] - 1)
+    LU = np.zeros(27 * 27)
+    lib.orc_coarse_matrix(O.P(LU), c, hf * 4)
+    lib.orc_lu_factor(O.P(LU), 27)
+    lib.orc_fill_boundary(O.P(H.u[-1]), Nf, hf)
+    want = [lib.orc_vcycle(H.ptrs(H.u), H.ptrs(H.d), H.ptrs(H.r), hf, L - 1, L, nu, Nf, O.P(LU)) for _ in range(4)]
+    assert [x[0] for x in val("VC9")] == pytest.approx(want, rel=1e-13)
+    su = 0.0
+    for p in range(Nf ** 3):
+        su += H.u[-1][p] * (1 + p % 11)
+    assert val("VC9U")[0][0] == su
+    assert val("TIMED")[0] == [4.0, 4.0]
+    assert re.search(r"beta\s+3\s", out)
+
+    # Solver facade
+    norms, _, init, _ = O.run_problem(5, 3, 2, 4)
+    lin = [x[0] for x in val("LIN")]
+    assert val("INIT")[0][0] == init
+    assert lin == pytest.approx(list(norms), rel=1e-13)
+    assert val("RES3")[0][0] == pytest.approx(norms[2], rel=1e-13)
+    assert re.search(r"LEVEL 2\n.*\n\s+Smoother1\s+1\s", out)  # reset before the 4th cycle

@@ -224,7 +224,7 @@ def test_legacy_host_vcycle_dirichlet_protocol(c, L, nu):
     got = []
     for _ in range(len(ref)):
         nrm = C.c_double(0)
-        check(M.lib().mg3d_host_vcycle(H.ptrs(H.u), H.ptrs(H.d), H.ptrs(H.r), h, L - 1, L, nu, N, P(LU), C.byref(nrm)))
+        check(M.lib().mg3d_host_vcycle(H.ptrs(H.u), H.ptrs(H.d), H.ptrs(H.r), h, L - 1, L, nu, N, P(LU), C.byref(nrm), None, None))
         got.append(nrm.value)
     np.testing.assert_allclose(got, ref, rtol=norm_rtol(N), atol=0)
     assert np.array_equal(H.u[-1][::97], V[f"usample_{key}"])
