@@ -26,12 +26,15 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.
 
 
 def algorithmic_bytes_per_cycle(c, L, nu, w=8):
-    """per level [3(nu1+nu2)+7]*n*w + 3*n_c*w, plus (n0^2+2 n0)*w for the LU solve."""
+    """SURVEY.md 8(d), summed from its per-operator figures: RB sweep 3n, residual+store 3n, residual norm
+    2n, restriction n+n_c, coarse zeroing n_c, prolong+correct n_c+2n  =>  per level
+    [3(nu1+nu2)+8]*n*w + 3*n_c*w, plus (n0^2+2 n0)*w for the LU solve.  (513^3, V(2,2): 25.18 GB, the figure
+    BASELINE.md quotes; SURVEY's bracketed "+7" is an off-by-one against its own component list.)"""
     tot = 0
     for l in range(1, L):
         n = ((c - 1) * (1 << l) + 1) ** 3
         nc = ((c - 1) * (1 << (l - 1)) + 1) ** 3
-        tot += (3 * (nu + nu) + 7) * n * w + 3 * nc * w
+        tot += (3 * (nu + nu) + 8) * n * w + 3 * nc * w
     n0 = c ** 3
     return tot + (n0 * n0 + 2 * n0) * w
 

@@ -76,6 +76,7 @@ struct Level {
     double h;
     size_t elems; /* doubles allocated per field */
     double *f[3]; /* u, d, r */
+    double *alt;  /* second copy of u: the fused sweep writes out of place, then the two are swapped */
 };
 
 struct StageTimer {
@@ -95,6 +96,7 @@ struct mg3d_ctx {
     double *sumsq;    /* device slots for squared norms */
     int sumsq_slots;
     double *h_sumsq;  /* pinned mirror */
+    bool fused; /* fused sweep kernel (default) or one launch per colour pass (MG3D_NO_FUSE=1) */
     int timing; /* 0 off, 1 every level, 2 finest level only */
     std::vector<StageTimer> timers; /* [L][MG3D_NUM_STAGES] */
     /* stage timing never stalls the stream: event pairs are recorded in-stream and
@@ -159,9 +161,13 @@ extern "C" int mg3d_ctx_destroy(mg3d_ctx *ctx)
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     for (auto &l : ctx->lv)
+    {
         for (int k = 0; k < 3; k++)
             if (l.f[k])
                 (void)hipFree(l.f[k]);
+        if (l.alt)
+            (void)hipFree(l.alt);
+    }
     free_lu(ctx);
     if (ctx->partials)
         (void)hipFree(ctx->partials);
@@ -195,7 +201,10 @@ static mg3d_ctx *ctx_new(int L, int iters)
     ctx->timers.assign((size_t)L * MG3D_NUM_STAGES, StageTimer{0, 0.});
     ctx->lv.resize(L);
     for (auto &l : ctx->lv)
-        l.f[0] = l.f[1] = l.f[2] = nullptr;
+        l.f[0] = l.f[1] = l.f[2] = l.alt = nullptr;
+    ctx->fused = true;
+    if (const char *e = getenv("MG3D_NO_FUSE"))
+        ctx->fused = !(e[0] == '1');
     return ctx;
 }
 
@@ -228,6 +237,8 @@ static int ctx_create_sizes(const int *n_per_level, const double *h_per_level, i
             CTXCHK(hipMalloc(&lev.f[k], lev.elems * sizeof(double)));
             CTXCHK(hipMemsetAsync(lev.f[k], 0, lev.elems * sizeof(double), ctx->stream)); /* calloc, mg_3d.h:44 */
         }
+        CTXCHK(hipMalloc(&lev.alt, lev.elems * sizeof(double)));
+        CTXCHK(hipMemsetAsync(lev.alt, 0, lev.elems * sizeof(double), ctx->stream));
     }
     CTXCHK(hipMalloc(&ctx->partials, MG3D_MAX_PARTIALS * sizeof(double)));
     ctx->sumsq_slots = 1024;
@@ -441,23 +452,57 @@ static int read_norm(mg3d_ctx *ctx, int slot, double *norm)
     return MG3D_OK;
 }
 
+/* iters x (two colour passes), optionally followed by the residual of the result.
+ * Fused path: chunks of 4 (or 2) passes per launch, each launch reading u and writing the
+ * alternate buffer; the residual rides on the last launch.  want_res: 0 none, 1 norm only,
+ * 2 store r (+ norm).  The squared norm goes to sumsq[slot]. */
+static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters, int want_res, int slot)
+{
+    Level &l = ctx->lv[level];
+    hipStream_t s = ctx->stream;
+    const int c1 = post ? 0 : 1; /* pre: red first (mg_3d.h:657); post: black first (mg_3d.h:728) */
+    if (ctx->fused) {
+        int passes = 2 * iters;
+        bool done_res = want_res == 0;
+        while (passes > 0 || !done_res) {
+            const int S = passes >= 4 ? 4 : passes; /* 4, 2 or 0 */
+            const bool last = passes - S == 0;
+            const bool res = last && want_res != 0;
+            const int np = k_sweep(l.g, l.f[MG3D_U], l.f[MG3D_D], l.alt, (res && want_res == 2) ? l.f[MG3D_R] : nullptr,
+                                   res ? ctx->partials : nullptr, MG3D_MAX_PARTIALS, l.h, S, c1, res, s);
+            if (S > 0) {
+                double *t = l.f[MG3D_U];
+                l.f[MG3D_U] = l.alt;
+                l.alt = t;
+            }
+            if (res) {
+                k_fold(ctx->partials, np, ctx->sumsq + slot, s);
+                done_res = true;
+            }
+            passes -= S;
+        }
+        return;
+    }
+    const double hSq = l.h * l.h; /* mg_3d.h:644 */
+    for (int it = 0; it < iters; it++) {
+        k_smooth_color(l.g, l.f[MG3D_U], l.f[MG3D_D], hSq, c1, s);
+        k_smooth_color(l.g, l.f[MG3D_U], l.f[MG3D_D], hSq, c1 ^ 1, s);
+    }
+    if (want_res) {
+        const double invHsq = 1. / (l.h * l.h); /* mg_3d.h:797 */
+        k_residual(l.g, l.f[MG3D_U], l.f[MG3D_D], invHsq, want_res == 2 ? l.f[MG3D_R] : nullptr, ctx->partials,
+                   ctx->sumsq + slot, s);
+    }
+}
+
 static void enqueue_smooth(mg3d_ctx *ctx, int level, int post, int iters)
 {
-    const Level &l = ctx->lv[level];
-    const double hSq = l.h * l.h; /* mg_3d.h:644 */
-    for (int s = 0; s < iters; s++) {
-        /* pre: red then black (mg_3d.h:657-702); post: black then red (mg_3d.h:728-773) */
-        k_smooth_color(l.g, l.f[MG3D_U], l.f[MG3D_D], hSq, post ? 0 : 1, ctx->stream);
-        k_smooth_color(l.g, l.f[MG3D_U], l.f[MG3D_D], hSq, post ? 1 : 0, ctx->stream);
-    }
+    enqueue_smooth_residual(ctx, level, post, iters, 0, 0);
 }
 
 static void enqueue_residual(mg3d_ctx *ctx, int level, int store, int slot)
 {
-    const Level &l = ctx->lv[level];
-    const double invHsq = 1. / (l.h * l.h); /* mg_3d.h:797 */
-    k_residual(l.g, l.f[MG3D_U], l.f[MG3D_D], invHsq, store ? l.f[MG3D_R] : nullptr, ctx->partials,
-               ctx->sumsq + slot, ctx->stream);
+    enqueue_smooth_residual(ctx, level, 0, 0, store ? 2 : 1, slot);
 }
 
 extern "C" int mg3d_smooth(mg3d_ctx *ctx, int level, int post, int iters)
@@ -551,11 +596,17 @@ static int enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
         Level &lev = ctx->lv[l];
         if (l < L - 1)
             (void)hipMemsetAsync(lev.f[MG3D_U], 0, lev.elems * sizeof(double), s); /* :1258-1259 */
-        {
-            StageScope t(ctx, l, MG3D_ST_SMOOTH1);
-            enqueue_smooth(ctx, l, 0, ctx->iters); /* :1282 */
-        }
-        {
+        if (ctx->fused) { /* pre-smoother and residual in one pass over the level (:1282 + :1294) */
+            {
+                StageScope t(ctx, l, MG3D_ST_SMOOTH1);
+                enqueue_smooth_residual(ctx, l, 0, ctx->iters, 2, ctx->sumsq_slots - 1);
+            }
+            StageScope t(ctx, l, MG3D_ST_RESIDUAL1); /* fused into the launch above: counted, ~0 s */
+        } else {
+            {
+                StageScope t(ctx, l, MG3D_ST_SMOOTH1);
+                enqueue_smooth(ctx, l, 0, ctx->iters); /* :1282 */
+            }
             StageScope t(ctx, l, MG3D_ST_RESIDUAL1);
             enqueue_residual(ctx, l, 1, ctx->sumsq_slots - 1); /* :1294 (norm discarded) */
         }
@@ -577,11 +628,17 @@ static int enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
             StageScope t(ctx, l, MG3D_ST_PROLONG);
             k_prolong(ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_U], lev.g, lev.f[MG3D_U], s); /* :1331 */
         }
-        {
-            StageScope t(ctx, l, MG3D_ST_SMOOTH2);
-            enqueue_smooth(ctx, l, 1, ctx->iters); /* :1341 */
-        }
-        {
+        if (ctx->fused) { /* post-smoother and residual norm in one pass (:1341 + :1354) */
+            {
+                StageScope t(ctx, l, MG3D_ST_SMOOTH2);
+                enqueue_smooth_residual(ctx, l, 1, ctx->iters, 1, l == q ? slot : ctx->sumsq_slots - 1);
+            }
+            StageScope t(ctx, l, MG3D_ST_RESIDUAL2); /* fused into the launch above: counted, ~0 s */
+        } else {
+            {
+                StageScope t(ctx, l, MG3D_ST_SMOOTH2);
+                enqueue_smooth(ctx, l, 1, ctx->iters); /* :1341 */
+            }
             StageScope t(ctx, l, MG3D_ST_RESIDUAL2);
             enqueue_residual(ctx, l, 0, l == q ? slot : ctx->sumsq_slots - 1); /* :1354 */
         }

@@ -40,6 +40,14 @@ void k_residual(const Geom &g, const double *v, const double *d, double invHsq, 
 void k_sumsq(const Geom &g, const double *a, double *partials, double *sumsq_out, hipStream_t s);
 void k_restrict(const Geom &gf, const double *r, const Geom &gc, double *dc, hipStream_t s);
 void k_prolong(const Geom &gc, const double *ec, const Geom &gf, double *ef, hipStream_t s);
+/* folds np per-block partial sums, in a fixed order, into *out */
+void k_fold(const double *partials, int np, double *out, hipStream_t s);
+/* fused sweep (mg3d_sweep.hip): S colour passes starting with colour c1 (1 red, 0 black) from vin into
+ * vout (vout != vin; ignored when S == 0), then optionally the residual of the result: r (may be NULL)
+ * receives it on the interior, partials (may be NULL) one sum of diff^2 per block.  Returns the number
+ * of partials written (>= 0) or -1 when the (S, residual) shape has no instantiation. */
+int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
+            int max_partials, double h, int S, int c1, bool residual, hipStream_t s);
 /* b and x are level-0 grids in the padded layout g0; work holds 2n doubles */
 void k_lu_solve(const LuBand &lu, const Geom &g0, const double *b_pad, double *x_pad, double *work, hipStream_t s);
 

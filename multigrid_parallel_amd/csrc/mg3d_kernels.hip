@@ -131,6 +131,11 @@ __global__ void __launch_bounds__(256) residual_kernel(Geom g, const double *__r
         partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tot;
 }
 
+void k_fold(const double *partials, int np, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, partials, np, out);
+}
+
 void k_residual(const Geom &g, const double *v, const double *d, double invHsq, double *res, double *partials,
                 double *sumsq_out, hipStream_t s)
 {

@@ -1,0 +1,355 @@
+/*
+ * mg3d_sweep.hip -- the fused, temporally blocked red-black Gauss-Seidel kernel.
+ *
+ * One launch streams a level ONCE through the chip and applies S consecutive
+ * colour passes (S = 2*nu: red,black,red,black for the pre-smoother,
+ * black,red,... for the post-smoother; mg_3d.h:640-781) and, optionally, the
+ * residual (mg_3d.h:794-842; r store and/or the L2 norm) on the smoothed field:
+ *      reads v, d once  ->  writes v' (and r) once.
+ * The separate-pass formulation moves 6*n*w bytes per RB sweep; this one moves
+ * 3*n*w for any number of fused sweeps.
+ *
+ * Every grid value is bit-identical to the reference: a colour pass only reads
+ * the other colour, so the result of a pass does not depend on traversal order,
+ * and each update evaluates the reference's expression (mg_3d.h:438-443)
+ * with the same association and no FMA contraction.
+ *
+ * ---- pipeline --------------------------------------------------------------
+ * A block owns a (j,k) tile and marches along i (planes of NJ x NK points).
+ * "Stage s" (s = 1..ST) is the s-th colour pass (or, for s > S, one half of the
+ * residual); at step p (plane p just loaded) stage s works on plane p-s.
+ * A point of plane q has colour (q+j+k)&1, hence column (j,k) is touched by
+ * stage s at step p iff (p+j+k) == c1+1 (mod 2) -- independent of s: at each
+ * step exactly one column of every k-pair is active, and it runs ALL stages
+ * (on planes p-1 .. p-ST).  Stage s needs from stage s-1:
+ *      i-1, i+1 : the thread's own column, two steps ago / this step (registers)
+ *      j-1, j+1 : the inactive column of the rows above/below, produced one
+ *                 step ago (registers: a thread owns RJ consecutive rows;
+ *                 LDS for the rows of the neighbouring wave)
+ *      k-1, k+1 : the pair partner (own register) and the neighbour lane's
+ *                 partner (one cross-lane move)
+ * so the whole window lives in registers; LDS only carries one row per wave
+ * edge and stage, and there is ONE barrier per plane.
+ *
+ * Geometry: a wave covers 64 k-pairs = 128 consecutive k; NW waves are stacked
+ * in j, each thread holding RJ rows: tile = (NW*RJ) x 128 points including a
+ * halo of H = S (+1 with residual) points on every side that is recomputed
+ * redundantly (halo loads hit L2: neighbouring tiles run on the same XCD).
+ * The i range is cut into chunks with ST warm-up planes each.  Output goes to a
+ * second array (the halo makes an in-place update racy between tiles).
+ */
+#include "mg3d_internal.h"
+
+#define WAVE 64
+
+struct SweepArgs {
+    Geom g;
+    const double *vin;
+    const double *d;
+    double *vout;     /* may equal nullptr when S == 0 */
+    double *r;        /* residual store (interior only) or nullptr */
+    double *partials; /* one partial sum of diff^2 per block, or nullptr */
+    double hSq, sixth, invHsq;
+    int c1;         /* colour of the first pass: 1 red, 0 black */
+    int ntj, ntk;   /* tiles in j, k */
+    int CI, nci;    /* planes per i-chunk, number of chunks */
+};
+
+template <int S, bool RES> struct SweepShape {
+    static constexpr int ST = S + (RES ? 2 : 0); /* pipeline stages */
+    static constexpr int HJ = S + (RES ? 1 : 0); /* halo rows */
+    static constexpr int HK = (HJ + 1) & ~1;     /* halo columns, even so pairs stay aligned */
+    static constexpr int HI = S + (RES ? 1 : 0); /* warm-up planes */
+};
+
+__device__ __forceinline__ double lane_from_left(double x) /* lane l receives lane l-1 */
+{
+    return __shfl_up(x, 1, WAVE);
+}
+__device__ __forceinline__ double lane_from_right(double x) /* lane l receives lane l+1 */
+{
+    return __shfl_down(x, 1, WAVE);
+}
+
+template <int S, bool RES, int RJ, int NW>
+__global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
+{
+    using Sh = SweepShape<S, RES>;
+    constexpr int ST = Sh::ST, HJ = Sh::HJ, HK = Sh::HK, HI = Sh::HI;
+    constexpr int TJ = NW * RJ, VJ = TJ - 2 * HJ, VK = 2 * WAVE - 2 * HK;
+    static_assert(RJ % 2 == 0, "RJ must be even (row parity of a wave's first row)");
+    static_assert(VJ > 0 && ST >= 1, "tile too small");
+    constexpr int STX = ST > 0 ? ST : 1;
+
+    /* edge rows exchanged between waves: [parity][wave][top/bottom][stage][lane] */
+    __shared__ double ex[2][NW][2][STX][WAVE];
+    __shared__ double red[NW];
+
+    const Geom &g = a.g;
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    int b = blockIdx.x;
+    const int tk = b % a.ntk;
+    b /= a.ntk;
+    const int tj = b % a.ntj;
+    const int ci = b / a.ntj;
+
+    const int jt0 = tj * VJ - HJ, kt0 = tk * VK - HK;
+    const int jrow0 = jt0 + w * RJ;
+    const int kA = kt0 + 2 * lane; /* column 0 of the pair; column 1 = kA + 1 */
+    const int i_out0 = ci * a.CI, i_out1 = min(i_out0 + a.CI, g.ni);
+    /* start plane: HI warm-up planes, one more if needed so that the column active at
+     * local step p in row rr is (p + rr) & 1 */
+    int i_s = i_out0 - HI;
+    i_s -= (g.ig0 + i_s + jt0 + 1 + a.c1) & 1;
+    const int nsteps = (i_out1 - 1 + ST) - i_s + 1;
+
+    /* per-row / per-column masks */
+    bool row_in[RJ], row_upd[RJ], row_own[RJ];
+    long long row_off[RJ];
+#pragma unroll
+    for (int rr = 0; rr < RJ; rr++) {
+        const int j = jrow0 + rr;
+        row_in[rr] = j >= 0 && j < g.nj;
+        row_upd[rr] = j >= 1 && j <= g.nj - 2;
+        row_own[rr] = row_in[rr] && j >= tj * VJ && j < (tj + 1) * VJ;
+        row_off[rr] = (long long)g.pitch * j + kA;
+    }
+    const bool col_in[2] = {kA >= 0 && kA < g.nk, kA + 1 >= 0 && kA + 1 < g.nk};
+    const bool col_upd[2] = {kA >= 1 && kA <= g.nk - 2, kA + 1 >= 1 && kA + 1 <= g.nk - 2};
+    const bool pair_own = kA >= tk * VK && kA < (tk + 1) * VK && col_in[0];
+    const bool pair_load = col_in[0]; /* kA even and pitch even: the 16-byte load stays inside the row */
+
+    /* pipeline state (see header).  last[rr][s][c]: newest stage-s output of column c */
+    double last[RJ][STX][2], in_prev[RJ][2], dring[RJ][ST + 1][2], rkeep[RJ];
+    double2 cur_v[RJ], nxt_v[RJ], nxt_d[RJ];
+#pragma unroll
+    for (int rr = 0; rr < RJ; rr++) {
+#pragma unroll
+        for (int s = 0; s < STX; s++)
+            last[rr][s][0] = last[rr][s][1] = 0.;
+#pragma unroll
+        for (int s = 0; s <= ST; s++)
+            dring[rr][s][0] = dring[rr][s][1] = 0.;
+        in_prev[rr][0] = in_prev[rr][1] = 0.;
+        rkeep[rr] = 0.;
+        cur_v[rr] = nxt_v[rr] = nxt_d[rr] = make_double2(0., 0.);
+    }
+    double acc = 0.;
+
+    auto load_plane = [&](int i, double2(&vv)[RJ], double2(&dd)[RJ]) {
+        const bool pl = i >= 0 && i < g.ni;
+#pragma unroll
+        for (int rr = 0; rr < RJ; rr++) {
+            if (pl && row_in[rr] && pair_load) {
+                const long long p = g.plane * i + row_off[rr];
+                vv[rr] = *reinterpret_cast<const double2 *>(a.vin + p);
+                dd[rr] = *reinterpret_cast<const double2 *>(a.d + p);
+            } else {
+                vv[rr] = make_double2(0., 0.);
+                dd[rr] = make_double2(0., 0.);
+            }
+        }
+    };
+
+    /* prime: plane i_s into nxt */
+    load_plane(i_s, nxt_v, nxt_d);
+
+    auto step = [&](int pl, auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;
+        const int i = i_s + pl; /* local plane just arrived */
+        const int par = pl & 1;
+        /* current plane <- prefetched, then prefetch the next one */
+#pragma unroll
+        for (int rr = 0; rr < RJ; rr++) {
+            cur_v[rr] = nxt_v[rr];
+            dring[rr][0][0] = nxt_d[rr].x;
+            dring[rr][0][1] = nxt_d[rr].y;
+        }
+        load_plane(i + 1, nxt_v, nxt_d);
+
+        /* rows of the neighbouring waves, written at the end of the previous step */
+        double e_top[STX], e_bot[STX];
+#pragma unroll
+        for (int s = 0; s < STX; s++) {
+            e_top[s] = (w > 0) ? ex[par ^ 1][w - 1][1][s][lane] : 0.;
+            e_bot[s] = (w < NW - 1) ? ex[par ^ 1][w + 1][0][s][lane] : 0.;
+        }
+        /* which planes may be updated (global boundary planes / slab halos are not) */
+        bool pl_upd[STX + 1];
+#pragma unroll
+        for (int s = 1; s <= ST; s++) {
+            const int q = i - s;
+            pl_upd[s] = q >= 1 && q <= g.ni - 2 && (g.ig0 + q) >= 1 && (g.ig0 + q) <= g.N - 2;
+        }
+
+#pragma unroll
+        for (int rr = 0; rr < RJ; rr++) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int X = (PAR + rr) & 1; /* active column of this row at this step */
+            double nw[STX + 1];
+            nw[0] = X ? cur_v[rr].y : cur_v[rr].x;
+            double diffs[2] = {0., 0.};
+#pragma unroll
+            for (int s = 1; s <= ST; s++) {
+                const double up = last[rr][s - 1][X]; /* plane q-1: two steps old */
+                const double dn = nw[s - 1];          /* plane q+1: this step */
+                const double jm = (rr > 0) ? last[rr - 1][s - 1][X] : e_top[s - 1];
+                const double jp = (rr < RJ - 1) ? last[rr + 1][s - 1][X] : e_bot[s - 1];
+                double km, kp;
+                if (X == 0) {
+                    km = lane_from_left(last[rr][s - 1][1]);
+                    kp = last[rr][s - 1][1];
+                } else {
+                    km = last[rr][s - 1][0];
+                    kp = lane_from_right(last[rr][s - 1][0]);
+                }
+                const double dd = dring[rr][s][X];
+                const double center = (s == 1) ? in_prev[rr][X] : last[rr][s - 2][X];
+                double sum = up + dn;
+                sum = sum + jm;
+                sum = sum + jp;
+                sum = sum + km;
+                sum = sum + kp;
+                const bool upd = row_upd[rr] && col_upd[X] && pl_upd[s];
+                if (s <= S) {
+                    const double val = a.sixth * (sum - a.hSq * dd); /* mg_3d.h:438-443 */
+                    nw[s] = upd ? val : center;
+                } else {
+                    const double diff = dd - a.invHsq * (sum - 6 * center); /* mg_3d.h:819-821 */
+                    nw[s] = center;
+                    diffs[s - S - 1] = diff;
+                    const int q = i - s;
+                    if (upd && row_own[rr] && pair_own && q >= i_out0 && q < i_out1)
+                        acc += diff * diff;
+                }
+            }
+            /* ---- stores: v' of plane i-S, r of plane i-S-2 (pairs complete at this step) */
+            if constexpr (S > 0) {
+                const int q = i - S;
+                if (q >= i_out0 && q < i_out1 && row_own[rr] && pair_own) {
+                    const double other = last[rr][S - 1][X ^ 1]; /* finished one step ago */
+                    double2 o;
+                    o.x = X ? other : nw[S];
+                    o.y = X ? nw[S] : other;
+                    *reinterpret_cast<double2 *>(a.vout + g.plane * q + row_off[rr]) = o;
+                }
+            }
+            if constexpr (RES) {
+                const int q = i - ST;
+                if (a.r && q >= i_out0 && q < i_out1 && row_own[rr] && pair_own && row_upd[rr] && pl_upd[ST]) {
+                    /* column X: stage S+2 now; column X^1: stage S+1 one step ago */
+                    double2 o;
+                    o.x = X ? rkeep[rr] : diffs[1];
+                    o.y = X ? diffs[1] : rkeep[rr];
+                    double *dst = a.r + g.plane * q + row_off[rr];
+                    if (col_upd[0] && col_upd[1])
+                        *reinterpret_cast<double2 *>(dst) = o;
+                    else if (col_upd[0])
+                        dst[0] = o.x;
+                    else if (col_upd[1])
+                        dst[1] = o.y; /* boundary entries of r are never written (mg_3d.h:824-825) */
+                }
+                rkeep[rr] = diffs[0];
+            }
+            /* ---- commit this row's new outputs */
+            in_prev[rr][0] = cur_v[rr].x;
+            in_prev[rr][1] = cur_v[rr].y;
+#pragma unroll
+            for (int s = 0; s < ST; s++)
+                last[rr][s][X] = nw[s];
+        }
+        /* age the d window */
+#pragma unroll
+        for (int rr = 0; rr < RJ; rr++)
+#pragma unroll
+            for (int s = ST; s >= 1; s--) {
+                dring[rr][s][0] = dring[rr][s - 1][0];
+                dring[rr][s][1] = dring[rr][s - 1][1];
+            }
+        /* publish this wave's edge rows for the next step */
+#pragma unroll
+        for (int s = 0; s < ST; s++) {
+            ex[par][w][0][s][lane] = last[0][s][(PAR + 0) & 1];
+            ex[par][w][1][s][lane] = last[RJ - 1][s][(PAR + RJ - 1) & 1];
+        }
+        __syncthreads();
+    };
+
+    int pl = 0;
+    for (; pl + 1 < nsteps; pl += 2) {
+        step(pl, std::integral_constant<int, 0>{});
+        step(pl + 1, std::integral_constant<int, 1>{});
+    }
+    if (pl < nsteps)
+        step(pl, std::integral_constant<int, 0>{});
+
+    if (RES && a.partials) {
+#pragma unroll
+        for (int off = WAVE / 2; off > 0; off >>= 1)
+            acc += __shfl_down(acc, off, WAVE);
+        if (lane == 0)
+            red[w] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.;
+            for (int x = 0; x < NW; x++)
+                t += red[x];
+            a.partials[blockIdx.x] = t;
+        }
+    }
+}
+
+/* -------------------------------------------------------------------- launch */
+template <int S, bool RES, int RJ, int NW>
+static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
+{
+    using Sh = SweepShape<S, RES>;
+    constexpr int VJ = NW * RJ - 2 * Sh::HJ, VK = 2 * WAVE - 2 * Sh::HK;
+    const Geom &g = a.g;
+    a.ntj = (g.nj + VJ - 1) / VJ;
+    a.ntk = (g.nk + VK - 1) / VK;
+    /* enough blocks to fill the chip, but chunks long enough to amortise the warm-up planes */
+    int CI = 64;
+    while (CI > 16 && (long long)a.ntj * a.ntk * ((g.ni + CI - 1) / CI) < 1024)
+        CI /= 2;
+    if (CI > g.ni)
+        CI = g.ni;
+    a.CI = CI;
+    a.nci = (g.ni + CI - 1) / CI;
+    const long long nb = (long long)a.ntj * a.ntk * a.nci;
+    if (a.partials && nb > max_partials)
+        return -1;
+    hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
+    return (int)nb;
+}
+
+/* S colour passes starting with colour c1, optional residual.  Returns the number of
+ * partial sums written (0 when no norm was requested), -1 if the shape is unsupported. */
+int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
+            int max_partials, double h, int S, int c1, bool residual, hipStream_t s)
+{
+    SweepArgs a;
+    a.g = g;
+    a.vin = vin;
+    a.d = d;
+    a.vout = vout;
+    a.r = r;
+    a.partials = partials;
+    a.hSq = h * h;           /* mg_3d.h:644 */
+    a.sixth = 1. / 6;        /* mg_3d.h:646 */
+    a.invHsq = 1. / (h * h); /* mg_3d.h:797 */
+    a.c1 = c1;
+    int nb = -1;
+    if (S == 4 && residual)
+        nb = launch_sweep<4, true, 4, 8>(a, max_partials, s);
+    else if (S == 4 && !residual)
+        nb = launch_sweep<4, false, 4, 8>(a, max_partials, s);
+    else if (S == 2 && residual)
+        nb = launch_sweep<2, true, 4, 8>(a, max_partials, s);
+    else if (S == 2 && !residual)
+        nb = launch_sweep<2, false, 4, 8>(a, max_partials, s);
+    else if (S == 0 && residual)
+        nb = launch_sweep<0, true, 4, 8>(a, max_partials, s);
+    return nb;
+}

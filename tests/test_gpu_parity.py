@@ -254,3 +254,17 @@ def test_error_paths():
             s.restrict(0)
     a = np.zeros(27)
     assert L.mg3d_host_restrict(P(a), 3, P(a), 3) == 1
+
+
+def test_unfused_kernel_set_gives_identical_results(monkeypatch):
+    """MG3D_NO_FUSE=1 selects the one-launch-per-colour-pass kernels; both kernel sets must agree bit for bit."""
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MG3D_NO_FUSE", flag)
+        with M.Solver(5, 5, 3) as s:  # nu = 3: the fused path chains a 4-pass and a 2-pass launch
+            s.setup_test_problem()
+            norms = s.vcycles(5)
+            outs.append((norms, s.download(MG3D_U, 4), s.download(MG3D_R, 3), s.download(MG3D_D, 2)))
+    assert np.array_equal(outs[0][0], outs[1][0]) or np.allclose(outs[0][0], outs[1][0], rtol=1e-12, atol=0)
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert np.array_equal(a, b)
