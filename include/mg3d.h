@@ -85,6 +85,9 @@ int mg3d_device_view(mg3d_ctx *ctx, int field, int level, void **dev_ptr, int *p
  * mg3d_l2norm     : GetL2NormOfVector over all N^3 entries (mg_3d.h:783-792) */
 int mg3d_smooth(mg3d_ctx *ctx, int level, int post, int iters);
 int mg3d_residual(mg3d_ctx *ctx, int level, int store, double *norm);
+/* smoother followed by the residual of its result, as vcycle does back to back (mg_3d.h:1282+1294,
+ * 1341+1354), in ONE pass over the level (fused sweep kernel) */
+int mg3d_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters, int store, double *norm);
 int mg3d_restrict(mg3d_ctx *ctx, int level);
 int mg3d_prolong(mg3d_ctx *ctx, int level);
 int mg3d_coarse_solve(mg3d_ctx *ctx);

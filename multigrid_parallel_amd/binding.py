@@ -47,6 +47,7 @@ SIGNATURES = {
                                    C.POINTER(C.c_long)]),
     "mg3d_smooth": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mg3d_residual": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
+    "mg3d_smooth_residual": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp]),
     "mg3d_restrict": (C.c_int, [C.c_void_p, C.c_int]),
     "mg3d_prolong": (C.c_int, [C.c_void_p, C.c_int]),
     "mg3d_coarse_solve": (C.c_int, [C.c_void_p]),
@@ -208,6 +209,12 @@ class Solver:
     def residual(self, level, store=True, want_norm=True):
         nrm = C.c_double(0)
         check(self.L.mg3d_residual(self._h, level, int(store), C.byref(nrm) if want_norm else None))
+        return nrm.value
+
+    def smooth_residual(self, level, post, iters, store=True, want_norm=True):
+        nrm = C.c_double(0)
+        check(self.L.mg3d_smooth_residual(self._h, level, int(post), iters, int(store),
+                                          C.byref(nrm) if want_norm else None))
         return nrm.value
 
     def restrict(self, level):
