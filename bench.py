@@ -155,7 +155,7 @@ def main():
 
     solver.vcycles(args.warmup)
     solver.timing_reset()
-    solver.timing_enable(2)  # event pairs around the finest-level stages only; no host stall
+    solver.timing_enable(1 if args.breakdown else 2)  # event pairs around the finest-level stages only; no host stall
     barrier()
     t0 = time.perf_counter()
     norms = solver.vcycles(args.steps)

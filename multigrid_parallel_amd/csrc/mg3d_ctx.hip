@@ -147,6 +147,10 @@ static void free_lu(mg3d_ctx *ctx)
         (void)hipFree(ctx->lu.ucol);
     if (ctx->lu.diag)
         (void)hipFree(ctx->lu.diag);
+    if (ctx->lu.lrot)
+        (void)hipFree(ctx->lu.lrot);
+    if (ctx->lu.urot)
+        (void)hipFree(ctx->lu.urot);
     if (ctx->lu_work)
         (void)hipFree(ctx->lu_work);
     memset(&ctx->lu, 0, sizeof ctx->lu);
@@ -331,6 +335,26 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
     HIPCHK(hipMemcpy(ctx->lu.lcol, lcol.data(), lcol.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->lu.ucol, ucol.data(), ucol.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->lu.diag, diag.data(), diag.size() * sizeof(double), hipMemcpyHostToDevice));
+    /* narrow bands (coarse grids up to 11^3): lane-rotated copies for the single-wave kernel */
+    const int R = (bw + 63) / 64;
+    if (R <= 2 && 3 * (size_t)n * sizeof(double) <= 60000) {
+        std::vector<double> lrot((size_t)n * 64 * R, 0.), urot((size_t)n * 64 * R, 0.);
+        for (long long j = 0; j < n; j++)
+            for (int q = 0; q < R; q++)
+                for (int l = 0; l < 64; l++) {
+                    const int tf = (int)((l - j - 1) & 63) + 64 * q, tb = (int)((j - 1 - l) & 63) + 64 * q;
+                    const long long irow_f = j + 1 + tf, irow_b = j - 1 - tb;
+                    if (tf < bw && irow_f < n)
+                        lrot[(size_t)j * 64 * R + 64 * q + l] = LU[irow_f * n + j];
+                    if (tb < bw && irow_b >= 0)
+                        urot[(size_t)j * 64 * R + 64 * q + l] = LU[irow_b * n + j];
+                }
+        HIPCHK(hipMalloc(&ctx->lu.lrot, lrot.size() * sizeof(double)));
+        HIPCHK(hipMalloc(&ctx->lu.urot, urot.size() * sizeof(double)));
+        HIPCHK(hipMemcpy(ctx->lu.lrot, lrot.data(), lrot.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->lu.urot, urot.data(), urot.size() * sizeof(double), hipMemcpyHostToDevice));
+        ctx->lu.rot_r = R;
+    }
     return MG3D_OK;
 }
 
@@ -644,7 +668,9 @@ static int enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
         if (ctx->fused) { /* post-smoother and residual norm in one pass (:1341 + :1354) */
             {
                 StageScope t(ctx, l, MG3D_ST_SMOOTH2);
-                enqueue_smooth_residual(ctx, l, 1, ctx->iters, 1, l == q ? slot : ctx->sumsq_slots - 1);
+                /* the norm of a level below the top one is computed and dropped by the reference (:1320
+                 * ignores the recursive call's value): skip it, nothing observable changes */
+                enqueue_smooth_residual(ctx, l, 1, ctx->iters, l == q ? 1 : 0, slot);
             }
             StageScope t(ctx, l, MG3D_ST_RESIDUAL2); /* fused into the launch above: counted, ~0 s */
         } else {
@@ -653,7 +679,8 @@ static int enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
                 enqueue_smooth(ctx, l, 1, ctx->iters); /* :1341 */
             }
             StageScope t(ctx, l, MG3D_ST_RESIDUAL2);
-            enqueue_residual(ctx, l, 0, l == q ? slot : ctx->sumsq_slots - 1); /* :1354 */
+            if (l == q)
+                enqueue_residual(ctx, l, 0, slot); /* :1354; below the top level the value is dropped (:1320) */
         }
     }
     return launch_ok("mg3d_vcycle");

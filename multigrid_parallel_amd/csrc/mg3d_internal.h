@@ -28,6 +28,12 @@ struct LuBand {
     double *lcol; /* [n][bw]  lcol[j*bw+t] = LU[j+1+t][j]   (strictly lower, by column) */
     double *ucol; /* [n][bw]  ucol[j*bw+t] = LU[j-1-t][j]   (strictly upper, by column) */
     double *diag; /* [n] */
+    /* lane-rotated copies for the single-wave solve (bw <= 64*rot_r): entry [j][64*q + l] is the
+     * factor of the row lane l accumulates at step j: forward row j+1+((l-j-1)&63)+64q, backward row
+     * j-1-((j-1-l)&63)-64q; zero outside the band / matrix */
+    int rot_r;    /* 0 when not built */
+    double *lrot; /* [n][64*rot_r] */
+    double *urot; /* [n][64*rot_r] */
 };
 
 #define MG3D_MAX_PARTIALS 8192

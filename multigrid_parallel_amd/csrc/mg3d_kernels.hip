@@ -318,20 +318,6 @@ void k_prolong(const Geom &gc, const double *ec, const Geom &gf, double *ef, hip
  * One wave: lane l owns rows == l (mod 64); with bw <= 64*R a lane has at most
  * R rows in flight, their running sums live in registers, x[j] travels by
  * v_readlane.  No LDS traffic on the dependency chain, no barriers. */
-template <int R, bool FWD>
-__device__ __forceinline__ void lu_wave_load(const LuBand &lu, int j, int lane, double (&dst)[R])
-{
-    const double *col = (FWD ? lu.lcol : lu.ucol) + (long long)j * lu.bw;
-    const int t0 = FWD ? ((lane - j - 1) & 63) : ((j - 1 - lane) & 63);
-#pragma unroll
-    for (int q = 0; q < R; q++) {
-        const int t = t0 + 64 * q;
-        const int i = FWD ? j + 1 + t : j - 1 - t;
-        const bool ok = j >= 0 && j < lu.n && t < lu.bw && i >= 0 && i < lu.n;
-        dst[q] = ok ? col[t] : 0.;
-    }
-}
-
 __device__ __forceinline__ double readlane_f64(double x, int lane_uniform)
 {
     const long long b = __double_as_longlong(x);
@@ -340,31 +326,42 @@ __device__ __forceinline__ double readlane_f64(double x, int lane_uniform)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-/* One substitution pass.  rhs/out/dg are dense LDS vectors.  Everything that does not
- * depend on the solution -- the factor's columns, rhs[j], the diagonal -- is fetched a
- * chunk (U steps) ahead, and x[j] travels by v_readlane, so the dependency chain per
- * step is: subtract (-> divide) -> readlane -> multiply -> add. */
+/* One substitution pass of the single-wave solve.  Lane l owns the rows == l (mod 64); acc[0] is the
+ * running sum of the row it finalises next, acc[1..] of the rows 64, 128, .. further on.  At step j
+ * the owner lane (j & 63) turns its acc[0] into x[j]; v_readlane broadcasts it; every lane then adds
+ * factor * x[j] to each of its sums (the owner first rotates its sums by one).  The factors come
+ * pre-rotated so that lane l always reads element l of the step's column: no index arithmetic and no
+ * predicates on the dependency chain  acc -> sub (-> div) -> readlane -> mul -> add.
+ * Columns, rhs[j] and the diagonal are fetched U steps ahead (they do not depend on the solution). */
 template <int R, bool FWD>
 __device__ __forceinline__ void lu_wave_pass(const LuBand &lu, int lane, const double *rhs, double *out,
                                              const double *dg)
 {
     constexpr int U = 8;
     const int n = lu.n;
-    double S[R];
+    const double *cols = (FWD ? lu.lrot : lu.urot) + lane;
+    double acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++)
-        S[r] = 0.;
+        acc[r] = 0.;
     double nxt[U][R], cur[U][R], rj[U], dj[U];
-    const int nch = (n + U - 1) / U;
+    auto fetch = [&](int step, double(&dst)[R]) {
+        int j = FWD ? step : n - 1 - step;
+        j = j < 0 ? 0 : (j >= n ? n - 1 : j); /* steps past the end: any valid column, never used */
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            dst[r] = cols[(long long)j * (64 * R) + 64 * r];
+    };
 #pragma unroll
     for (int u = 0; u < U; u++)
-        lu_wave_load<R, FWD>(lu, FWD ? u : n - 1 - u, lane, nxt[u]);
+        fetch(u, nxt[u]);
+    const int nch = (n + U - 1) / U;
     for (int c = 0; c < nch; c++) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
 #pragma unroll
-            for (int q = 0; q < R; q++)
-                cur[u][q] = nxt[u][q];
+            for (int r = 0; r < R; r++)
+                cur[u][r] = nxt[u][r];
             const int step = c * U + u;
             const int j = FWD ? step : n - 1 - step;
             const bool in = step < n;
@@ -372,42 +369,25 @@ __device__ __forceinline__ void lu_wave_pass(const LuBand &lu, int lane, const d
             dj[u] = (!FWD && in) ? dg[j] : 1.;
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int jn = (c + 1) * U + u;
-            lu_wave_load<R, FWD>(lu, FWD ? jn : n - 1 - jn, lane, nxt[u]); /* out-of-range steps load 0 */
-        }
+        for (int u = 0; u < U; u++)
+            fetch((c + 1) * U + u, nxt[u]);
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int step = c * U + u;
             if (step >= n)
                 break;
             const int j = FWD ? step : n - 1 - step;
-            const int owner = j & 63, slot = (j >> 6) % R;
-            double mine = S[0];
-#pragma unroll
-            for (int r = 1; r < R; r++)
-                mine = (r == slot) ? S[r] : mine;
-            double cand = rj[u] - mine;
+            const int owner = j & 63;
+            double cand = rj[u] - acc[0]; /* gauss_elim.h:46 / :57 */
             if (!FWD)
                 cand = cand / dj[u];
             const double xj = readlane_f64(cand, owner);
+            out[j] = xj; /* every lane stores the same value to the same LDS word */
             const bool own = lane == owner;
-            if (own)
-                out[j] = xj;
 #pragma unroll
-            for (int r = 0; r < R; r++)
-                S[r] = (own && r == slot) ? 0. : S[r]; /* the slot now belongs to the row 64*R further on */
-            const int t0 = FWD ? ((lane - j - 1) & 63) : ((j - 1 - lane) & 63);
-#pragma unroll
-            for (int q = 0; q < R; q++) {
-                const int t = t0 + 64 * q;
-                const int i = FWD ? j + 1 + t : j - 1 - t;
-                const bool ok = t < lu.bw && i >= 0 && i < n;
-                const double prod = cur[u][q] * xj;
-                const int sl = (i >> 6) % R;
-#pragma unroll
-                for (int r = 0; r < R; r++)
-                    S[r] = (ok && r == sl) ? S[r] + prod : S[r];
+            for (int r = 0; r < R; r++) {
+                const double base = own ? (r + 1 < R ? acc[r + 1] : 0.) : acc[r];
+                acc[r] = base + cur[u][r] * xj; /* sum += LU[i][j]*x[j], gauss_elim.h:41,55 */
             }
         }
     }
@@ -488,9 +468,9 @@ void k_lu_solve(const LuBand &lu, const Geom &g0, const double *b_pad, double *x
 {
     double *z = work, *acc = work + lu.n;
     const size_t lds = sizeof(double) * 3 * (size_t)lu.n;
-    if (lu.bw <= 64 && lds <= 60000)
+    if (lu.rot_r == 1)
         hipLaunchKernelGGL(lu_solve_wave_kernel<1>, dim3(1), dim3(64), lds, s, lu, g0, b_pad, x_pad);
-    else if (lu.bw <= 128 && lds <= 60000)
+    else if (lu.rot_r == 2)
         hipLaunchKernelGGL(lu_solve_wave_kernel<2>, dim3(1), dim3(64), lds, s, lu, g0, b_pad, x_pad);
     else
         hipLaunchKernelGGL(lu_solve_block_kernel, dim3(1), dim3(1024), 0, s, lu, g0, b_pad, x_pad, z, acc);

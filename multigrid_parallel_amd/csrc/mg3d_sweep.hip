@@ -353,12 +353,17 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
     const Geom &g = a.g;
     a.ntj = (g.nj + VJ - 1) / VJ;
     a.ntk = (g.nk + VK - 1) / VK;
-    /* enough blocks to fill the chip, but chunks long enough to amortise the warm-up planes */
-    int CI = 64;
-    if (const char *e = getenv("MG3D_SWEEP_CI"))
-        CI = atoi(e);
-    while (CI > 16 && (long long)a.ntj * a.ntk * ((g.ni + CI - 1) / CI) < 1024)
+    /* i-chunk length: every chunk pays ST warm-up planes, but a level needs a few hundred blocks to keep
+     * 256 CUs busy and short chunks mean fewer dependent steps.  Measured optimum on MI355X: about
+     * 500-1000 blocks (513^3: CI 64-128, 257^3: 16, 129^3: 8, <= 65^3: 2-4). */
+    auto blocks = [&](int ci) { return (long long)a.ntj * a.ntk * ((g.ni + ci - 1) / ci); };
+    int CI = 8;
+    while (CI < 128 && blocks(CI) > 800)
+        CI *= 2;
+    while (CI > 2 && blocks(CI) < 100)
         CI /= 2;
+    if (const char *e = getenv("MG3D_SWEEP_CI"))
+        CI = atoi(e) > 0 ? atoi(e) : CI;
     if (CI > g.ni)
         CI = g.ni;
     a.CI = CI;
