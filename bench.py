@@ -168,23 +168,40 @@ def main():
         elapsed = float(t.item())
 
     tm = solver.timing()
+    kt = solver.kernel_times()
     fin = L - 1
+    n_f = N ** 3
     sm_calls = tm[(fin, "Smoother1")][0] + tm[(fin, "Smoother2")][0]
     sm_secs = tm[(fin, "Smoother1")][1] + tm[(fin, "Smoother2")][1]
-    n_f = N ** 3
-    info = M.lib().mg3d_kernel_info() if hasattr(M.lib(), "mg3d_kernel_info") else None
-    launches_per_call = 2 * nu  # colour passes per smoother call in the baseline kernel set
-    bytes_per_launch = 1.5 * n_f * 8  # full RB sweep = 3*n*w, one colour pass = half
-    dur = sm_secs / max(1, sm_calls * launches_per_call)
+    # dominant kernel: the fused sweep at the finest level (4 colour passes = 2 RB sweeps per launch when
+    # nu is even; 2 passes per launch otherwise).  Algorithmic bytes per launch, SURVEY 8(d): an RB sweep
+    # (red + black pass) is credited 3*n*w bytes, so a launch fusing P colour passes is credited 1.5*P*n*w.
+    if (fin, "sweep4") in kt:
+        kname, passes = "sweep4", 4
+        kernel = "sweep_kernel<4,false,4,8,1> (4 fused colour passes = 2 RB sweeps, finest level)"
+    elif (fin, "sweep2") in kt:
+        kname, passes = "sweep2", 2
+        kernel = "sweep_kernel<2,false,4,8,1> (2 fused colour passes = 1 RB sweep, finest level)"
+    elif (fin, "sweep2+residual") in kt:
+        kname, passes = "sweep2+residual", 2
+        kernel = "sweep_kernel<2,true,4,8,1> (1 RB sweep + residual, finest level)"
+    else:
+        kname, passes = "colour_pass", 1
+        kernel = "smooth_color_kernel (one colour pass, finest level)"
+    launches, ksecs = kt[(fin, kname)]
+    bytes_per_launch = 1.5 * passes * n_f * 8
+    if kname == "sweep2+residual":
+        bytes_per_launch += 3.0 * n_f * 8  # residual with store: 3*n*w
+    dur = ksecs / max(1, launches)
     achieved = bytes_per_launch / dur / 1e9 if dur > 0 else 0.0
-    roof = {"bound": "hbm", "kernel": "smooth_color_kernel (one red or black pass, finest level)",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": dur * 1e3,
-            "launches_timed": sm_calls * launches_per_call}
+    roof = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_per_launch,
+            "avg_launch_ms": dur * 1e3, "launches_timed": launches,
+            "physical_bytes_per_launch_min": 3.0 * n_f * 8}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            roof["traffic"] = json.load(open(pmc)).get("smooth_color_kernel")
+            roof["traffic"] = json.load(open(pmc)).get(kname)
         except Exception:
             pass
 
@@ -210,6 +227,8 @@ def main():
             for (lvl, st), (calls, secs) in sorted(tm.items()):
                 if calls:
                     print(f"level {lvl} {st:24s} calls {calls:5d}  {secs * 1e3 / calls:9.4f} ms/call", file=sys.stderr)
+            for (lvl, kn), (calls, secs) in sorted(kt.items()):
+                print(f"kernel level {lvl} {kn:18s} launches {calls:5d}  {secs * 1e3 / calls:9.4f} ms/launch", file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             solver.finalize()
             line["cpu_baseline"] = run_cpu_baseline(args)

@@ -105,6 +105,17 @@ int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms);
 int mg3d_timing_enable(mg3d_ctx *ctx, int on);
 int mg3d_timing_reset(mg3d_ctx *ctx);
 int mg3d_timing_get(mg3d_ctx *ctx, int level, int stage, int *num_calls, double *seconds);
+/* per-kernel timers, same mechanism, one event pair around each launch of the kernels below */
+enum {
+    MG3D_K_SWEEP4 = 0,   /* fused sweep, 4 colour passes */
+    MG3D_K_SWEEP2,       /* fused sweep, 2 colour passes */
+    MG3D_K_SWEEP2_RES,   /* fused sweep, 2 colour passes + residual */
+    MG3D_K_RESIDUAL,     /* residual (+ r store) of the current field */
+    MG3D_K_RESTRICT, MG3D_K_PROLONG, MG3D_K_COARSE_SOLVE, MG3D_K_COLOUR_PASS,
+    MG3D_NUM_KERNELS
+};
+const char *mg3d_kernel_name(int kernel);
+int mg3d_kernel_time_get(mg3d_ctx *ctx, int level, int kernel, int *num_launches, double *seconds);
 
 /* ------------------------------------- host-pointer forms (reference signatures)
  * Same argument meaning as the reference functions; data is staged to the

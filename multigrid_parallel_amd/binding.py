@@ -57,6 +57,8 @@ SIGNATURES = {
     "mg3d_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mg3d_timing_reset": (C.c_int, [C.c_void_p]),
     "mg3d_timing_get": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), dp]),
+    "mg3d_kernel_name": (C.c_char_p, [C.c_int]),
+    "mg3d_kernel_time_get": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), dp]),
     "mg3d_host_smooth": (C.c_int, [dp, dp, C.c_int, C.c_double, C.c_int, C.c_int]),
     "mg3d_host_residual": (C.c_int, [dp, dp, C.c_int, C.c_double, dp, dp]),
     "mg3d_host_restrict": (C.c_int, [dp, C.c_int, dp, C.c_int]),
@@ -248,6 +250,16 @@ class Solver:
 
     def timing_reset(self):
         check(self.L.mg3d_timing_reset(self._h))
+
+    def kernel_times(self):
+        out = {}
+        for l in range(self.num_levels):
+            for k in range(8):
+                calls, secs = C.c_int(0), C.c_double(0)
+                check(self.L.mg3d_kernel_time_get(self._h, l, k, C.byref(calls), C.byref(secs)))
+                if calls.value:
+                    out[(l, self.L.mg3d_kernel_name(k).decode())] = (calls.value, secs.value)
+        return out
 
     def timing(self):
         out = {}

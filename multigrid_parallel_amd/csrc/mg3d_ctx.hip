@@ -50,6 +50,11 @@ static const char *const kStageNames[MG3D_NUM_STAGES] = {"Smoother1",          "
                                                          "Recurse, Direct Solve", "Prolongate&Correct", "Smoother2",
                                                          "CalcResidual2"}; /* mg_3d.h:136-137 */
 
+static const char *const kKernelNames[MG3D_NUM_KERNELS] = {"sweep4", "sweep2", "sweep2+residual", "residual",
+                                                           "restrict", "prolong", "coarse_solve", "colour_pass"};
+
+extern "C" const char *mg3d_kernel_name(int k) { return (k >= 0 && k < MG3D_NUM_KERNELS) ? kKernelNames[k] : "?"; }
+
 extern "C" const char *mg3d_stage_name(int stage)
 {
     return (stage >= 0 && stage < MG3D_NUM_STAGES) ? kStageNames[stage] : "?";
@@ -102,7 +107,7 @@ struct mg3d_ctx {
     /* stage timing never stalls the stream: event pairs are recorded in-stream and
      * resolved at the next host synchronisation the entry point does anyway */
     struct Pending {
-        int level, stage;
+        int slot; /* index into timers: stage timers first ([level][stage]), then kernel timers */
         hipEvent_t a, b;
     };
     std::vector<Pending> pending;
@@ -127,7 +132,7 @@ static void resolve_timers(mg3d_ctx *ctx)
     for (auto &p : ctx->pending) {
         float ms = 0.f;
         if (p.a && p.b && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            StageTimer &t = ctx->timers[(size_t)p.level * MG3D_NUM_STAGES + p.stage];
+            StageTimer &t = ctx->timers[(size_t)p.slot];
             t.calls++;
             t.seconds += ms * 1e-3;
         }
@@ -138,6 +143,30 @@ static void resolve_timers(mg3d_ctx *ctx)
     }
     ctx->pending.clear();
 }
+
+/* scoped event pair: a stage of the reference's timing table, or (kernel = true) one kernel launch */
+struct StageScope {
+    mg3d_ctx *ctx;
+    mg3d_ctx::Pending p;
+    bool on;
+    StageScope(mg3d_ctx *c, int l, int s, bool kernel = false) : ctx(c)
+    {
+        p.slot = kernel ? c->L * MG3D_NUM_STAGES + l * MG3D_NUM_KERNELS + s : l * MG3D_NUM_STAGES + s;
+        p.a = p.b = nullptr;
+        on = ctx->timing == 1 || (ctx->timing == 2 && l == ctx->L - 1);
+        if (on && (p.a = take_event(ctx)))
+            (void)hipEventRecord(p.a, ctx->stream);
+    }
+    ~StageScope()
+    {
+        if (!on)
+            return;
+        if ((p.b = take_event(ctx)))
+            (void)hipEventRecord(p.b, ctx->stream);
+        ctx->pending.push_back(p);
+    }
+};
+
 
 static void free_lu(mg3d_ctx *ctx)
 {
@@ -202,7 +231,7 @@ static mg3d_ctx *ctx_new(int L, int iters)
     ctx->sumsq_slots = 0;
     ctx->stream = nullptr;
     ctx->timing = 0;
-    ctx->timers.assign((size_t)L * MG3D_NUM_STAGES, StageTimer{0, 0.});
+    ctx->timers.assign((size_t)L * (MG3D_NUM_STAGES + MG3D_NUM_KERNELS), StageTimer{0, 0.});
     ctx->lv.resize(L);
     for (auto &l : ctx->lv)
         l.f[0] = l.f[1] = l.f[2] = l.alt = nullptr;
@@ -495,8 +524,13 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
              * window leaves too few registers for a tile with a useful interior: measured 1.9 ms fused
              * against 0.85 + 0.76 ms split on a 513^3 level) */
             const bool res = last && want_res != 0 && S != 4;
-            const int np = k_sweep(l.g, l.f[MG3D_U], l.f[MG3D_D], l.alt, (res && want_res == 2) ? l.f[MG3D_R] : nullptr,
-                                   res ? ctx->partials : nullptr, MG3D_MAX_PARTIALS, l.h, S, c1, res, s);
+            int np;
+            {
+                StageScope kt(ctx, level, S == 4 ? MG3D_K_SWEEP4 : S == 2 ? (res ? MG3D_K_SWEEP2_RES : MG3D_K_SWEEP2)
+                                                                          : MG3D_K_RESIDUAL, true);
+                np = k_sweep(l.g, l.f[MG3D_U], l.f[MG3D_D], l.alt, (res && want_res == 2) ? l.f[MG3D_R] : nullptr,
+                             res ? ctx->partials : nullptr, MG3D_MAX_PARTIALS, l.h, S, c1, res, s);
+            }
             if (S > 0) {
                 double *t = l.f[MG3D_U];
                 l.f[MG3D_U] = l.alt;
@@ -511,12 +545,13 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
         return;
     }
     const double hSq = l.h * l.h; /* mg_3d.h:644 */
-    for (int it = 0; it < iters; it++) {
-        k_smooth_color(l.g, l.f[MG3D_U], l.f[MG3D_D], hSq, c1, s);
-        k_smooth_color(l.g, l.f[MG3D_U], l.f[MG3D_D], hSq, c1 ^ 1, s);
+    for (int it = 0; it < 2 * iters; it++) {
+        StageScope kt(ctx, level, MG3D_K_COLOUR_PASS, true);
+        k_smooth_color(l.g, l.f[MG3D_U], l.f[MG3D_D], hSq, c1 ^ (it & 1), s);
     }
     if (want_res) {
         const double invHsq = 1. / (l.h * l.h); /* mg_3d.h:797 */
+        StageScope kt(ctx, level, MG3D_K_RESIDUAL, true);
         k_residual(l.g, l.f[MG3D_U], l.f[MG3D_D], invHsq, want_res == 2 ? l.f[MG3D_R] : nullptr, ctx->partials,
                    ctx->sumsq + slot, s);
     }
@@ -598,29 +633,6 @@ extern "C" int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm)
 }
 
 /* ------------------------------------------------------------------ V-cycle */
-struct StageScope {
-    mg3d_ctx *ctx;
-    mg3d_ctx::Pending p;
-    bool on;
-    StageScope(mg3d_ctx *c, int l, int s) : ctx(c)
-    {
-        p.level = l;
-        p.stage = s;
-        p.a = p.b = nullptr;
-        on = ctx->timing == 1 || (ctx->timing == 2 && l == ctx->L - 1);
-        if (on && (p.a = take_event(ctx)))
-            (void)hipEventRecord(p.a, ctx->stream);
-    }
-    ~StageScope()
-    {
-        if (!on)
-            return;
-        if ((p.b = take_event(ctx)))
-            (void)hipEventRecord(p.b, ctx->stream);
-        ctx->pending.push_back(p);
-    }
-};
-
 /* vcycle, mg_3d.h:1242-1362, unrolled: descend q..1, solve level 0, ascend 1..q.
  * The squared post-smoothing norm of level q goes to sumsq[slot]. */
 static int enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
@@ -649,6 +661,7 @@ static int enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
         }
         {
             StageScope t(ctx, l, MG3D_ST_RESTRICT);
+            StageScope kt(ctx, l, MG3D_K_RESTRICT, true);
             k_restrict(lev.g, lev.f[MG3D_R], ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_D], s); /* :1310 */
         }
     }
@@ -657,12 +670,14 @@ static int enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
         if (0 < L - 1)
             (void)hipMemsetAsync(l0.f[MG3D_U], 0, l0.elems * sizeof(double), s);
         StageScope t(ctx, 0, MG3D_ST_RECURSE);
+        StageScope kt(ctx, 0, MG3D_K_COARSE_SOLVE, true);
         k_lu_solve(ctx->lu, l0.g, l0.f[MG3D_D], l0.f[MG3D_U], ctx->lu_work, s); /* :1270 */
     }
     for (int l = 1; l <= q; l++) {
         Level &lev = ctx->lv[l];
         {
             StageScope t(ctx, l, MG3D_ST_PROLONG);
+            StageScope kt(ctx, l, MG3D_K_PROLONG, true);
             k_prolong(ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_U], lev.g, lev.f[MG3D_U], s); /* :1331 */
         }
         if (ctx->fused) { /* post-smoother and residual norm in one pass (:1341 + :1354) */
@@ -747,6 +762,22 @@ extern "C" int mg3d_timing_reset(mg3d_ctx *ctx) /* resetTimingInfo, timing_info.
     }
     for (auto &t : ctx->timers)
         t = StageTimer{0, 0.};
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_kernel_time_get(mg3d_ctx *ctx, int level, int kernel, int *num_launches, double *seconds)
+{
+    if (!ctx || level < 0 || level >= ctx->L || kernel < 0 || kernel >= MG3D_NUM_KERNELS)
+        return fail(MG3D_ERR_ARG, "mg3d_kernel_time_get: bad level/kernel");
+    if (!ctx->pending.empty()) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        resolve_timers(ctx);
+    }
+    const StageTimer &t = ctx->timers[(size_t)ctx->L * MG3D_NUM_STAGES + (size_t)level * MG3D_NUM_KERNELS + kernel];
+    if (num_launches)
+        *num_launches = t.calls;
+    if (seconds)
+        *seconds = t.seconds;
     return MG3D_OK;
 }
 
@@ -911,7 +942,7 @@ extern "C" int mg3d_host_vcycle(double **u, double **f, double **res, double h, 
     CHK(read_norm(ctx, 0, &nrm)); /* synchronises and resolves the stage timers */
     if (norm)
         *norm = nrm;
-    for (size_t t = 0; t < ctx->timers.size(); t++) {
+    for (size_t t = 0; t < (size_t)ctx->L * MG3D_NUM_STAGES; t++) {
         if (stage_calls)
             stage_calls[t] += ctx->timers[t].calls;
         if (stage_seconds)
