@@ -117,6 +117,31 @@ enum {
 const char *mg3d_kernel_name(int kernel);
 int mg3d_kernel_time_get(mg3d_ctx *ctx, int level, int kernel, int *num_launches, double *seconds);
 
+/* ------------------------------------------------------------ several GPUs (i-slabs)
+ * The reference splits every operator over the slowest index i between OpenMP threads (mg_3d.h:658-659);
+ * here rank r of nranks (one process per GPU) owns a contiguous range of i-planes of every level large
+ * enough, exchanges halo planes with its two neighbours by RCCL send/recv, and the small levels plus the
+ * direct solve are replicated after one all-gather of the restricted right-hand side.  See
+ * csrc/mg3d_dist.hip.  unique_id: 128 bytes from mg3d_comm_unique_id() on rank 0, distributed by the
+ * launcher; NULL selects the loopback transport (all ranks virtual, in this process, on `device`).
+ * mg3d_dist_upload/download take the FULL N^3 host array; a rank reads its slab / writes its owned planes. */
+typedef struct mg3d_dist mg3d_dist;
+int mg3d_comm_unique_id(void *out128);
+int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters, double grid_length, int rank, int nranks,
+                     const void *unique_id, int device, mg3d_dist **out);
+int mg3d_dist_destroy(mg3d_dist *d);
+int mg3d_dist_first_level(const mg3d_dist *d); /* lowest distributed level */
+int mg3d_dist_halo(const mg3d_dist *d);        /* halo planes per side */
+int mg3d_dist_build_coarse(mg3d_dist *d, double h_coarse);
+int mg3d_dist_upload(mg3d_dist *d, int field, int level, const double *host_full);
+int mg3d_dist_download(mg3d_dist *d, int field, int level, double *host_full);
+int mg3d_dist_vcycles(mg3d_dist *d, int count, double *norms);
+int mg3d_dist_sync(mg3d_dist *d);
+/* the partition itself (pure host arithmetic, usable without a GPU) */
+int mg3d_slab_halo(int smooth_iters);
+int mg3d_slab_first_level(int coarse_pts, int num_levels, int nranks, int halo);
+int mg3d_slab_owned(int coarse_pts, int num_levels, int nranks, int halo, int level, int rank, int *lo, int *hi);
+
 /* ------------------------------------- host-pointer forms (reference signatures)
  * Same argument meaning as the reference functions; data is staged to the
  * device, computed there, and copied back.  They exist so that drivers that

@@ -59,6 +59,21 @@ SIGNATURES = {
     "mg3d_timing_get": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), dp]),
     "mg3d_kernel_name": (C.c_char_p, [C.c_int]),
     "mg3d_kernel_time_get": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), dp]),
+    "mg3d_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mg3d_dist_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                   C.POINTER(C.c_void_p)]),
+    "mg3d_dist_destroy": (C.c_int, [C.c_void_p]),
+    "mg3d_dist_first_level": (C.c_int, [C.c_void_p]),
+    "mg3d_dist_halo": (C.c_int, [C.c_void_p]),
+    "mg3d_dist_build_coarse": (C.c_int, [C.c_void_p, C.c_double]),
+    "mg3d_dist_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
+    "mg3d_dist_download": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
+    "mg3d_dist_vcycles": (C.c_int, [C.c_void_p, C.c_int, dp]),
+    "mg3d_dist_sync": (C.c_int, [C.c_void_p]),
+    "mg3d_slab_halo": (C.c_int, [C.c_int]),
+    "mg3d_slab_first_level": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mg3d_slab_owned": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int)]),
     "mg3d_host_smooth": (C.c_int, [dp, dp, C.c_int, C.c_double, C.c_int, C.c_int]),
     "mg3d_host_residual": (C.c_int, [dp, dp, C.c_int, C.c_double, dp, dp]),
     "mg3d_host_restrict": (C.c_int, [dp, C.c_int, dp, C.c_int]),
@@ -269,3 +284,76 @@ class Solver:
                 check(self.L.mg3d_timing_get(self._h, l, s, C.byref(calls), C.byref(secs)))
                 out[(l, self.L.mg3d_stage_name(s).decode())] = (calls.value, secs.value)
         return out
+
+
+class DistSolver:
+    """V-cycle on i-slabs: rank `rank` of `nranks` (one process per GPU, RCCL), or -- unique_id=None -- all ranks
+    virtual in this process on one GPU (loopback transport; used to verify the decomposition)."""
+
+    def __init__(self, coarse_pts, num_levels, smooth_iters, rank=0, nranks=1, unique_id=None, device=0,
+                 grid_length=1.0):
+        self.L = lib()
+        self._h = C.c_void_p()
+        uid = None if unique_id is None else C.c_char_p(bytes(unique_id))
+        check(self.L.mg3d_dist_create(coarse_pts, num_levels, smooth_iters, grid_length, rank, nranks, uid, device,
+                                      C.byref(self._h)))
+        self.c, self.num_levels, self.nu, self.rank, self.nranks = coarse_pts, num_levels, smooth_iters, rank, nranks
+        self.N = (coarse_pts - 1) * (1 << (num_levels - 1)) + 1
+        self.h = grid_length / (self.N - 1)
+        self.first_level = self.L.mg3d_dist_first_level(self._h)
+        self.halo = self.L.mg3d_dist_halo(self._h)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().mg3d_comm_unique_id(buf))
+        return buf.raw
+
+    def close(self):
+        if self._h:
+            check(self.L.mg3d_dist_destroy(self._h))
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def level_n(self, level):
+        return (self.c - 1) * (1 << level) + 1
+
+    def setup_test_problem(self):
+        """test_mg_3d.c:11-29 on the full grid; every rank takes its slab."""
+        check(self.L.mg3d_dist_build_coarse(self._h, self.h * (1 << (self.num_levels - 1))))
+        full = np.zeros(self.N ** 3)
+        self.L.mg3d_fill_boundary_host(P(full), self.N, self.h)
+        fin = self.num_levels - 1
+        self.upload(MG3D_D, fin, full)
+        self.upload(MG3D_U, fin, full)
+        return float(np.sqrt((full * full).sum()))
+
+    def upload(self, field, level, host_full):
+        host_full = np.ascontiguousarray(host_full, dtype=np.float64).reshape(-1)
+        assert host_full.size == self.level_n(level) ** 3
+        check(self.L.mg3d_dist_upload(self._h, field, level, P(host_full)))
+
+    def download(self, field, level, out=None):
+        n = self.level_n(level)
+        out = np.zeros(n ** 3) if out is None else out
+        check(self.L.mg3d_dist_download(self._h, field, level, P(out)))
+        return out
+
+    def vcycles(self, count):
+        norms = np.zeros(count)
+        check(self.L.mg3d_dist_vcycles(self._h, count, P(norms)))
+        return norms
+
+    def sync(self):
+        check(self.L.mg3d_dist_sync(self._h))

@@ -1,0 +1,53 @@
+/* mg3d_ctx.h -- solver context internals shared by mg3d_ctx.hip and mg3d_dist.hip (not installed). */
+#ifndef MG3D_CTX_H
+#define MG3D_CTX_H
+
+#include <vector>
+
+#include "mg3d_internal.h"
+
+struct Level {
+    Geom g;
+    double h;
+    size_t elems; /* doubles allocated per field */
+    double *f[3]; /* u, d, r */
+    double *alt;  /* second copy of u: the fused sweep writes out of place, then the two are swapped */
+};
+
+struct StageTimer {
+    int calls;
+    double seconds;
+};
+
+struct mg3d_ctx {
+    int c, L, iters;
+    double length;
+    std::vector<Level> lv;
+    hipStream_t stream;
+    bool own_stream; /* false when a distributed driver shares one stream between contexts */
+    LuBand lu;
+    bool have_lu;
+    double *lu_work;  /* 2n doubles */
+    double *partials; /* MG3D_MAX_PARTIALS doubles */
+    double *sumsq;    /* device slots for squared norms */
+    int sumsq_slots;
+    double *h_sumsq;  /* pinned mirror */
+    bool fused; /* fused sweep kernel (default) or one launch per colour pass (MG3D_NO_FUSE=1) */
+    int timing; /* 0 off, 1 every level, 2 finest level only */
+    std::vector<StageTimer> timers; /* [L][MG3D_NUM_STAGES] */
+    /* stage timing never stalls the stream: event pairs are recorded in-stream and
+     * resolved at the next host synchronisation the entry point does anyway */
+    struct Pending {
+        int slot; /* index into timers: stage timers first ([level][stage]), then kernel timers */
+        hipEvent_t a, b;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+/* records a failure text for mg3d_last_error() and returns `code` */
+int mg3d_fail(int code, const char *fmt, ...);
+/* enqueue one V-cycle from level q of a (single-domain) context; squared norm of level q to sumsq[slot] */
+int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot);
+
+#endif

@@ -7,7 +7,7 @@
  * synchronisations are the ones an entry point's contract requires (returning
  * a norm, copying data back).
  */
-#include "mg3d_internal.h"
+#include "mg3d_ctx.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -20,7 +20,7 @@
 /* ------------------------------------------------------------------ errors */
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, ...)
+int mg3d_fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -28,6 +28,7 @@ static int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
+#define fail mg3d_fail
 
 #define HIPCHK(call)                                                                                       \
     do {                                                                                                   \
@@ -76,44 +77,6 @@ static int require_device(void)
 }
 
 /* ----------------------------------------------------------------- context */
-struct Level {
-    Geom g;
-    double h;
-    size_t elems; /* doubles allocated per field */
-    double *f[3]; /* u, d, r */
-    double *alt;  /* second copy of u: the fused sweep writes out of place, then the two are swapped */
-};
-
-struct StageTimer {
-    int calls;
-    double seconds;
-};
-
-struct mg3d_ctx {
-    int c, L, iters;
-    double length;
-    std::vector<Level> lv;
-    hipStream_t stream;
-    LuBand lu;
-    bool have_lu;
-    double *lu_work;  /* 2n doubles */
-    double *partials; /* MG3D_MAX_PARTIALS doubles */
-    double *sumsq;    /* device slots for squared norms */
-    int sumsq_slots;
-    double *h_sumsq;  /* pinned mirror */
-    bool fused; /* fused sweep kernel (default) or one launch per colour pass (MG3D_NO_FUSE=1) */
-    int timing; /* 0 off, 1 every level, 2 finest level only */
-    std::vector<StageTimer> timers; /* [L][MG3D_NUM_STAGES] */
-    /* stage timing never stalls the stream: event pairs are recorded in-stream and
-     * resolved at the next host synchronisation the entry point does anyway */
-    struct Pending {
-        int slot; /* index into timers: stage timers first ([level][stage]), then kernel timers */
-        hipEvent_t a, b;
-    };
-    std::vector<Pending> pending;
-    std::vector<hipEvent_t> event_pool;
-};
-
 static hipEvent_t take_event(mg3d_ctx *ctx)
 {
     hipEvent_t e = nullptr;
@@ -211,7 +174,7 @@ extern "C" int mg3d_ctx_destroy(mg3d_ctx *ctx)
     resolve_timers(ctx);
     for (hipEvent_t e : ctx->event_pool)
         (void)hipEventDestroy(e);
-    if (ctx->stream)
+    if (ctx->stream && ctx->own_stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MG3D_OK;
@@ -230,6 +193,7 @@ static mg3d_ctx *ctx_new(int L, int iters)
     ctx->partials = ctx->sumsq = ctx->h_sumsq = nullptr;
     ctx->sumsq_slots = 0;
     ctx->stream = nullptr;
+    ctx->own_stream = true;
     ctx->timing = 0;
     ctx->timers.assign((size_t)L * (MG3D_NUM_STAGES + MG3D_NUM_KERNELS), StageTimer{0, 0.});
     ctx->lv.resize(L);
@@ -635,7 +599,7 @@ extern "C" int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm)
 /* ------------------------------------------------------------------ V-cycle */
 /* vcycle, mg_3d.h:1242-1362, unrolled: descend q..1, solve level 0, ascend 1..q.
  * The squared post-smoothing norm of level q goes to sumsq[slot]. */
-static int enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
+int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
 {
     if (!ctx->have_lu)
         return fail(MG3D_ERR_STATE, "mg3d_vcycle: no coarse LU set (mg3d_ctx_build_coarse / mg3d_ctx_set_lu)");
@@ -710,7 +674,7 @@ extern "C" int mg3d_vcycle(mg3d_ctx *ctx, int level, double *norm)
             *norm = 0.;
         return MG3D_OK;
     }
-    CHK(enqueue_vcycle(ctx, level, 0));
+    CHK(mg3d_enqueue_vcycle(ctx, level, 0));
     return read_norm(ctx, 0, norm);
 }
 
@@ -731,7 +695,7 @@ extern "C" int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms)
     for (int done = 0; done < count;) {
         const int nb = (count - done < batch) ? count - done : batch;
         for (int c = 0; c < nb; c++)
-            CHK(enqueue_vcycle(ctx, q, c));
+            CHK(mg3d_enqueue_vcycle(ctx, q, c));
         HIPCHK(hipMemcpyAsync(ctx->h_sumsq, ctx->sumsq, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         resolve_timers(ctx);
@@ -937,7 +901,7 @@ extern "C" int mg3d_host_vcycle(double **u, double **f, double **res, double h, 
     }
     if (q < num_levels - 1) /* not the caller's finest level: its guess is zeroed first (:1258) */
         CHK(mg3d_zero(ctx, MG3D_U, q));
-    CHK(enqueue_vcycle(ctx, q, 0));
+    CHK(mg3d_enqueue_vcycle(ctx, q, 0));
     double nrm = 0.;
     CHK(read_norm(ctx, 0, &nrm)); /* synchronises and resolves the stage timers */
     if (norm)

@@ -1,0 +1,589 @@
+/*
+ * mg3d_dist.hip -- the V-cycle on i-slabs of several GPUs (one process per GPU, RCCL over xGMI).
+ *
+ * Partition: the reference's OpenMP path already splits every operator over the slowest index i
+ * (`#pragma omp for` over i, mg_3d.h:658-659); its implicit barriers become plane exchanges here.
+ * Rank r owns the global planes [b_l(r), b_l(r+1)) of level l, with b_{l+1} = 2*b_l, so coarse plane ic
+ * and fine plane 2*ic always have the same owner.  Levels too small to give every rank 8 planes are
+ * REPLICATED: the restricted right-hand side is all-gathered once per cycle and every rank runs the
+ * remaining levels (and the gauss_elim.h direct solve) redundantly on identical data -- what a gather to
+ * rank 0 followed by a broadcast would deliver, bit for bit, with one collective instead of two.
+ *
+ * Halo: H = 2*nu + 2 planes on each side.  The fused sweep applies S = 2*nu colour passes per launch; a
+ * slab end that is not refreshed between passes goes stale one plane per pass, so after a sweep the
+ * local planes [S, ni-S) are exact, the residual on [S+1, ni-S-1) -- which covers the owned planes and
+ * the one extra fine plane restriction needs (H = S+2).  Exchanges per distributed level and cycle:
+ * d of the next coarser level after restriction, u after prolongation (before post-smoothing); at the
+ * finest level also u after post-smoothing (the next cycle starts from it).  Planes are contiguous in
+ * memory, so a halo is one ncclSend/ncclRecv pair per neighbour, no packing.
+ *
+ * Transports: RCCL (ncclCommInitRank from a unique id the launcher distributes), or "loopback": all
+ * ranks are virtual, live in this process on one GPU and exchange by device copies -- the same
+ * schedule code, used to verify the decomposition bit for bit on a single-GPU box.
+ */
+#include "mg3d_ctx.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <rccl/rccl.h>
+
+#define fail mg3d_fail
+#define HIPCHK(call)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(MG3D_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                      \
+    } while (0)
+#define NCCLCHK(call)                                                                                    \
+    do {                                                                                                 \
+        ncclResult_t e_ = (call);                                                                        \
+        if (e_ != ncclSuccess)                                                                           \
+            return fail(MG3D_ERR_HIP, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                       \
+    } while (0)
+#define CHK(call)           \
+    do {                    \
+        int rc_ = (call);   \
+        if (rc_ != MG3D_OK) \
+            return rc_;     \
+    } while (0)
+
+/* ------------------------------------------------------------------------------------------ plan */
+extern "C" int mg3d_slab_halo(int smooth_iters) { return 2 * smooth_iters + 2; }
+
+/* first distributed level: every rank must own at least max(8, halo) planes there */
+extern "C" int mg3d_slab_first_level(int coarse_pts, int num_levels, int nranks, int halo)
+{
+    const int need = halo > 8 ? halo : 8;
+    for (int l = 1; l < num_levels; l++) {
+        const long long n1 = ((long long)(coarse_pts - 1) << l);
+        if (n1 / nranks >= need)
+            return l;
+    }
+    return num_levels; /* nothing can be distributed */
+}
+
+/* owned planes [lo, hi) of `rank` on `level` (level >= first distributed level) */
+extern "C" int mg3d_slab_owned(int coarse_pts, int num_levels, int nranks, int halo, int level, int rank, int *lo,
+                               int *hi)
+{
+    const int ld = mg3d_slab_first_level(coarse_pts, num_levels, nranks, halo);
+    if (level < ld || level >= num_levels || rank < 0 || rank >= nranks)
+        return MG3D_ERR_ARG;
+    const long long n1 = ((long long)(coarse_pts - 1) << ld); /* N-1 on level ld */
+    auto cut = [&](int r) -> long long {
+        if (r <= 0)
+            return 0;
+        const long long Nl = ((long long)(coarse_pts - 1) << level) + 1;
+        if (r >= nranks)
+            return Nl;
+        /* even cut on the first distributed level (its coarse partner ld-1 is split at exact halves),
+         * doubled per finer level: b_{l+1} = 2 b_l */
+        return ((((n1 / 2) * r) / nranks) * 2) << (level - ld);
+    };
+    *lo = (int)cut(rank);
+    *hi = (int)cut(rank + 1);
+    return MG3D_OK;
+}
+
+/* ------------------------------------------------------------------------------------- structures */
+struct SlabLevel {
+    Level lv;
+    int glo, ghi;         /* owned global planes */
+    int own_lo, own_hi;   /* the same in local plane indices */
+    int h_lo, h_hi;       /* halo planes below / above (0 at a physical boundary) */
+};
+
+struct RankState {
+    int rank;
+    std::vector<SlabLevel> dl; /* distributed levels ld .. L-1, index l - ld */
+    mg3d_ctx *coarse;          /* replicated levels 0 .. ld-1 */
+    double *gather;            /* P doubles: per-rank partial sums of squares */
+};
+
+struct mg3d_dist {
+    int c, L, nu, P, ld, H;
+    double length;
+    bool loopback;
+    int device;
+    ncclComm_t comm;
+    bool have_comm;
+    hipStream_t stream; /* every operation of every local rank is ordered on this one stream */
+    std::vector<RankState> rs;
+    double *h_norms; /* pinned */
+    double *d_norms; /* device: squared norms per cycle */
+    int norm_slots;
+    std::vector<double> spacing; /* per level */
+};
+
+static SlabLevel &SL(mg3d_dist *D, RankState &R, int l) { return R.dl[l - D->ld]; }
+
+__global__ void sum_in_order_kernel(const double *__restrict__ parts, int n, double *__restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double t = 0.;
+        for (int i = 0; i < n; i++)
+            t += parts[i];
+        *out = t;
+    }
+}
+
+extern "C" int mg3d_comm_unique_id(void *out128)
+{
+    if (!out128)
+        return fail(MG3D_ERR_ARG, "mg3d_comm_unique_id: NULL");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    ncclUniqueId id;
+    NCCLCHK(ncclGetUniqueId(&id));
+    memcpy(out128, &id, sizeof id);
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_dist_destroy(mg3d_dist *D)
+{
+    if (!D)
+        return MG3D_OK;
+    if (D->stream)
+        (void)hipStreamSynchronize(D->stream);
+    for (auto &R : D->rs) {
+        for (auto &s : R.dl) {
+            for (int k = 0; k < 3; k++)
+                if (s.lv.f[k])
+                    (void)hipFree(s.lv.f[k]);
+            if (s.lv.alt)
+                (void)hipFree(s.lv.alt);
+        }
+        if (R.gather)
+            (void)hipFree(R.gather);
+    }
+    /* contexts that borrow the shared stream go first, its owner last */
+    for (auto &R : D->rs)
+        if (R.coarse && !R.coarse->own_stream) {
+            mg3d_ctx_destroy(R.coarse);
+            R.coarse = nullptr;
+        }
+    for (auto &R : D->rs)
+        if (R.coarse)
+            mg3d_ctx_destroy(R.coarse);
+    if (D->d_norms)
+        (void)hipFree(D->d_norms);
+    if (D->h_norms)
+        (void)hipHostFree(D->h_norms);
+    if (D->have_comm)
+        (void)ncclCommDestroy(D->comm);
+    delete D;
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters, double grid_length, int rank,
+                                int nranks, const void *unique_id, int device, mg3d_dist **out)
+{
+    if (!out || coarse_pts < 3 || num_levels < 2 || smooth_iters < 1 || nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(MG3D_ERR_ARG, "mg3d_dist_create: bad arguments");
+    if (mg3d_device_count() <= 0)
+        return fail(MG3D_ERR_NO_DEVICE, "no HIP device available: libmg3d has no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    mg3d_dist *D = new mg3d_dist();
+    D->c = coarse_pts;
+    D->L = num_levels;
+    D->nu = smooth_iters;
+    D->P = nranks;
+    D->length = grid_length;
+    D->H = mg3d_slab_halo(smooth_iters);
+    D->ld = mg3d_slab_first_level(coarse_pts, num_levels, nranks, D->H);
+    D->loopback = unique_id == nullptr;
+    D->device = device;
+    D->have_comm = false;
+    D->stream = nullptr;
+    D->h_norms = D->d_norms = nullptr;
+    if (D->ld >= num_levels) {
+        delete D;
+        return fail(MG3D_ERR_ARG, "mg3d_dist_create: %d ranks leave no level with >= 8 planes per rank", nranks);
+    }
+    /* spacing per level: finest = length/(N-1), doubled per coarser level (mg_3d.h:143,1303) */
+    D->spacing.resize(num_levels);
+    const long long finest = ((long long)(coarse_pts - 1) << (num_levels - 1)) + 1;
+    D->spacing[num_levels - 1] = grid_length / (double)(finest - 1);
+    for (int l = num_levels - 2; l >= 0; l--)
+        D->spacing[l] = 2 * D->spacing[l + 1];
+#define DCHK(call)                                                                        \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            int rc_ = fail(e_ == hipErrorOutOfMemory ? MG3D_ERR_ALLOC : MG3D_ERR_HIP,    \
+                           "%s failed: %s", #call, hipGetErrorString(e_));                \
+            mg3d_dist_destroy(D);                                                         \
+            return rc_;                                                                   \
+        }                                                                                 \
+    } while (0)
+    const int first = D->loopback ? 0 : rank, last = D->loopback ? nranks : rank + 1;
+    for (int r = first; r < last; r++) {
+        RankState R;
+        R.rank = r;
+        R.coarse = nullptr;
+        R.gather = nullptr;
+        D->rs.push_back(R);
+    }
+    for (auto &R : D->rs) {
+        /* replicated part: an ordinary single-domain context of the ld lowest levels */
+        const int rc = mg3d_ctx_create(coarse_pts, D->ld, smooth_iters, 1.0, &R.coarse);
+        if (rc != MG3D_OK) {
+            mg3d_dist_destroy(D);
+            return rc;
+        }
+        for (int l = 0; l < D->ld; l++)
+            R.coarse->lv[l].h = D->spacing[l];
+        if (!D->stream)
+            D->stream = R.coarse->stream; /* shared by all local ranks: one ordered queue */
+        else {
+            (void)hipStreamDestroy(R.coarse->stream);
+            R.coarse->stream = D->stream;
+            R.coarse->own_stream = false;
+        }
+        DCHK(hipMalloc(&R.gather, sizeof(double) * nranks));
+        R.dl.resize(num_levels - D->ld);
+        for (int l = D->ld; l < num_levels; l++) {
+            SlabLevel &s = R.dl[l - D->ld];
+            for (int k = 0; k < 3; k++)
+                s.lv.f[k] = nullptr;
+            s.lv.alt = nullptr;
+            mg3d_slab_owned(coarse_pts, num_levels, nranks, D->H, l, R.rank, &s.glo, &s.ghi);
+            const int N = (coarse_pts - 1) * (1 << l) + 1;
+            s.h_lo = R.rank > 0 ? D->H : 0;
+            s.h_hi = R.rank < nranks - 1 ? D->H : 0;
+            Geom &g = s.lv.g;
+            g.N = N;
+            g.nj = g.nk = N;
+            g.ig0 = s.glo - s.h_lo;
+            g.ni = (s.ghi - s.glo) + s.h_lo + s.h_hi;
+            g.pitch = mg3d_pitch_for(N);
+            g.plane = (long long)g.pitch * N;
+            s.own_lo = s.h_lo;
+            s.own_hi = s.h_lo + (s.ghi - s.glo);
+            s.lv.h = D->spacing[l];
+            s.lv.elems = (size_t)g.plane * g.ni;
+            for (int k = 0; k < 3; k++) {
+                DCHK(hipMalloc(&s.lv.f[k], s.lv.elems * sizeof(double)));
+                DCHK(hipMemsetAsync(s.lv.f[k], 0, s.lv.elems * sizeof(double), D->stream));
+            }
+            DCHK(hipMalloc(&s.lv.alt, s.lv.elems * sizeof(double)));
+            DCHK(hipMemsetAsync(s.lv.alt, 0, s.lv.elems * sizeof(double), D->stream));
+        }
+    }
+    D->norm_slots = 1024;
+    DCHK(hipMalloc(&D->d_norms, sizeof(double) * D->norm_slots));
+    DCHK(hipHostMalloc(&D->h_norms, sizeof(double) * D->norm_slots));
+    DCHK(hipStreamSynchronize(D->stream));
+#undef DCHK
+    if (!D->loopback && nranks > 1) {
+        ncclUniqueId id;
+        memcpy(&id, unique_id, sizeof id);
+        ncclResult_t e = ncclCommInitRank(&D->comm, nranks, id, rank);
+        if (e != ncclSuccess) {
+            const int rc = fail(MG3D_ERR_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString(e));
+            mg3d_dist_destroy(D);
+            return rc;
+        }
+        D->have_comm = true;
+    }
+    *out = D;
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_dist_first_level(const mg3d_dist *D) { return D ? D->ld : -1; }
+extern "C" int mg3d_dist_halo(const mg3d_dist *D) { return D ? D->H : -1; }
+
+extern "C" int mg3d_dist_build_coarse(mg3d_dist *D, double h_coarse)
+{
+    if (!D)
+        return fail(MG3D_ERR_ARG, "mg3d_dist_build_coarse: NULL");
+    for (auto &R : D->rs)
+        CHK(mg3d_ctx_build_coarse(R.coarse, h_coarse));
+    return MG3D_OK;
+}
+
+/* ------------------------------------------------------------------------------------ data movement */
+static int dist_field_ptr(mg3d_dist *D, RankState &R, int field, int level, double **ptr, Geom *g)
+{
+    if (field < 0 || field > 2 || level < 0 || level >= D->L)
+        return fail(MG3D_ERR_ARG, "mg3d_dist: bad field/level (%d, %d)", field, level);
+    if (level >= D->ld) {
+        *ptr = SL(D, R, level).lv.f[field];
+        *g = SL(D, R, level).lv.g;
+    } else {
+        *ptr = R.coarse->lv[level].f[field];
+        *g = R.coarse->lv[level].g;
+    }
+    return MG3D_OK;
+}
+
+/* host is the FULL N^3 array (reference layout); every local rank takes its slab (halos included) */
+extern "C" int mg3d_dist_upload(mg3d_dist *D, int field, int level, const double *host)
+{
+    if (!D || !host)
+        return fail(MG3D_ERR_ARG, "mg3d_dist_upload: NULL");
+    for (auto &R : D->rs) {
+        double *p;
+        Geom g;
+        CHK(dist_field_ptr(D, R, field, level, &p, &g));
+        const int N = g.N;
+        HIPCHK(hipMemcpy2DAsync(p, g.pitch * sizeof(double), host + (size_t)g.ig0 * N * N, N * sizeof(double),
+                                N * sizeof(double), (size_t)g.ni * N, hipMemcpyHostToDevice, D->stream));
+    }
+    HIPCHK(hipStreamSynchronize(D->stream));
+    return MG3D_OK;
+}
+
+/* writes the planes each local rank OWNS into the full host array (other planes untouched) */
+extern "C" int mg3d_dist_download(mg3d_dist *D, int field, int level, double *host)
+{
+    if (!D || !host)
+        return fail(MG3D_ERR_ARG, "mg3d_dist_download: NULL");
+    for (auto &R : D->rs) {
+        double *p;
+        Geom g;
+        CHK(dist_field_ptr(D, R, field, level, &p, &g));
+        const int N = g.N;
+        int lo = 0, hi = g.ni, glo = 0;
+        if (level >= D->ld) {
+            SlabLevel &s = SL(D, R, level);
+            lo = s.own_lo;
+            hi = s.own_hi;
+            glo = s.glo;
+        }
+        HIPCHK(hipMemcpy2DAsync(host + (size_t)glo * N * N, N * sizeof(double), p + g.plane * lo,
+                                g.pitch * sizeof(double), N * sizeof(double), (size_t)(hi - lo) * N,
+                                hipMemcpyDeviceToHost, D->stream));
+    }
+    HIPCHK(hipStreamSynchronize(D->stream));
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_dist_sync(mg3d_dist *D)
+{
+    if (!D)
+        return fail(MG3D_ERR_ARG, "mg3d_dist_sync: NULL");
+    HIPCHK(hipStreamSynchronize(D->stream));
+    return MG3D_OK;
+}
+
+/* --------------------------------------------------------------------------------------- transport */
+/* refresh the H halo planes of `field` on distributed level l from the neighbours' owned planes */
+static int exchange_halo(mg3d_dist *D, int field, int l)
+{
+    hipStream_t s = D->stream;
+    const int H = D->H;
+    if (D->P == 1)
+        return MG3D_OK;
+    if (D->loopback) {
+        for (int r = 0; r + 1 < D->P; r++) {
+            SlabLevel &a = SL(D, D->rs[r], l), &b = SL(D, D->rs[r + 1], l);
+            const size_t bytes = (size_t)H * a.lv.g.plane * sizeof(double);
+            /* r's upper halo <- first H owned planes of r+1 ; (r+1)'s lower halo <- last H owned planes of r */
+            HIPCHK(hipMemcpyAsync(a.lv.f[field] + a.lv.g.plane * a.own_hi, b.lv.f[field] + b.lv.g.plane * b.own_lo,
+                                  bytes, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(b.lv.f[field] + b.lv.g.plane * (b.own_lo - H),
+                                  a.lv.f[field] + a.lv.g.plane * (a.own_hi - H), bytes, hipMemcpyDeviceToDevice, s));
+        }
+        return MG3D_OK;
+    }
+    RankState &R = D->rs[0];
+    SlabLevel &a = SL(D, R, l);
+    const size_t cnt = (size_t)H * a.lv.g.plane;
+    double *f = a.lv.f[field];
+    NCCLCHK(ncclGroupStart());
+    if (R.rank + 1 < D->P) {
+        NCCLCHK(ncclSend(f + a.lv.g.plane * (a.own_hi - H), cnt, ncclDouble, R.rank + 1, D->comm, s));
+        NCCLCHK(ncclRecv(f + a.lv.g.plane * a.own_hi, cnt, ncclDouble, R.rank + 1, D->comm, s));
+    }
+    if (R.rank > 0) {
+        NCCLCHK(ncclSend(f + a.lv.g.plane * a.own_lo, cnt, ncclDouble, R.rank - 1, D->comm, s));
+        NCCLCHK(ncclRecv(f + a.lv.g.plane * (a.own_lo - H), cnt, ncclDouble, R.rank - 1, D->comm, s));
+    }
+    NCCLCHK(ncclGroupEnd());
+    return MG3D_OK;
+}
+
+/* every rank ends up with the complete d of the first replicated level (ld-1); rank r computed the
+ * planes [b(r), b(r+1)) of it (b of level ld halved) */
+static int allgather_coarse_rhs(mg3d_dist *D)
+{
+    hipStream_t s = D->stream;
+    const int lc = D->ld - 1;
+    if (D->P == 1)
+        return MG3D_OK;
+    auto range = [&](int r, int *lo, int *hi) {
+        int flo, fhi;
+        mg3d_slab_owned(D->c, D->L, D->P, D->H, D->ld, r, &flo, &fhi);
+        const int Nc = D->rs[0].coarse->lv[lc].g.N;
+        *lo = r == 0 ? 0 : flo / 2;
+        *hi = r == D->P - 1 ? Nc : fhi / 2;
+    };
+    if (D->loopback) {
+        for (int src = 0; src < D->P; src++) {
+            int lo, hi;
+            range(src, &lo, &hi);
+            const Geom &g = D->rs[src].coarse->lv[lc].g;
+            const size_t bytes = (size_t)(hi - lo) * g.plane * sizeof(double);
+            for (int dst = 0; dst < D->P; dst++)
+                if (dst != src)
+                    HIPCHK(hipMemcpyAsync(D->rs[dst].coarse->lv[lc].f[MG3D_D] + g.plane * lo,
+                                          D->rs[src].coarse->lv[lc].f[MG3D_D] + g.plane * lo, bytes,
+                                          hipMemcpyDeviceToDevice, s));
+        }
+        return MG3D_OK;
+    }
+    RankState &R = D->rs[0];
+    const Geom &g = R.coarse->lv[lc].g;
+    double *buf = R.coarse->lv[lc].f[MG3D_D];
+    NCCLCHK(ncclGroupStart());
+    for (int root = 0; root < D->P; root++) {
+        int lo, hi;
+        range(root, &lo, &hi);
+        NCCLCHK(ncclBroadcast(buf + g.plane * lo, buf + g.plane * lo, (size_t)(hi - lo) * g.plane, ncclDouble, root,
+                              D->comm, s));
+    }
+    NCCLCHK(ncclGroupEnd());
+    return MG3D_OK;
+}
+
+/* total = sum over ranks (in rank order, so every rank gets the same bits) of each rank's sumsq[0] */
+static int reduce_norm(mg3d_dist *D, int slot)
+{
+    hipStream_t s = D->stream;
+    if (D->loopback) {
+        RankState &R0 = D->rs[0];
+        for (int r = 0; r < D->P; r++)
+            HIPCHK(hipMemcpyAsync(R0.gather + r, D->rs[r].coarse->sumsq, sizeof(double), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(sum_in_order_kernel, dim3(1), dim3(64), 0, s, R0.gather, D->P, D->d_norms + slot);
+        return MG3D_OK;
+    }
+    RankState &R = D->rs[0];
+    if (D->P > 1)
+        NCCLCHK(ncclAllGather(R.coarse->sumsq, R.gather, 1, ncclDouble, D->comm, s));
+    else
+        HIPCHK(hipMemcpyAsync(R.gather, R.coarse->sumsq, sizeof(double), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(sum_in_order_kernel, dim3(1), dim3(64), 0, s, R.gather, D->P, D->d_norms + slot);
+    return MG3D_OK;
+}
+
+/* ----------------------------------------------------------------------------------------- V-cycle */
+/* iters x two colour passes on a slab level, optional residual (2: store r, 1: norm only into the rank's
+ * coarse->sumsq[0] over OWNED planes).  Same launch policy as the single-domain path. */
+static void slab_smooth_residual(mg3d_dist *D, RankState &R, int l, int post, int want_res)
+{
+    SlabLevel &sl = SL(D, R, l);
+    Level &lv = sl.lv;
+    hipStream_t s = D->stream;
+    mg3d_ctx *cx = R.coarse;
+    const int c1 = post ? 0 : 1;
+    int passes = 2 * D->nu;
+    bool done_res = want_res == 0;
+    while (passes > 0 || !done_res) {
+        const int S = passes >= 4 ? 4 : passes;
+        const bool last = passes - S == 0;
+        const bool res = last && want_res != 0 && S != 4;
+        const int np = k_sweep(lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt, (res && want_res == 2) ? lv.f[MG3D_R] : nullptr,
+                               res ? cx->partials : nullptr, MG3D_MAX_PARTIALS, lv.h, S, c1, res, s, sl.own_lo,
+                               sl.own_hi);
+        if (S > 0) {
+            double *t = lv.f[MG3D_U];
+            lv.f[MG3D_U] = lv.alt;
+            lv.alt = t;
+        }
+        if (res) {
+            k_fold(cx->partials, np, cx->sumsq, s);
+            done_res = true;
+        }
+        passes -= S;
+    }
+}
+
+static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
+{
+    hipStream_t s = D->stream;
+    const int L = D->L, ld = D->ld;
+    for (auto &R : D->rs)
+        if (!R.coarse->have_lu)
+            return fail(MG3D_ERR_STATE, "mg3d_dist_vcycles: no coarse LU set (mg3d_dist_build_coarse)");
+    /* ---- down: distributed levels */
+    for (int l = L - 1; l >= ld; l--) {
+        for (auto &R : D->rs) {
+            SlabLevel &sl = SL(D, R, l);
+            if (l < L - 1)
+                (void)hipMemsetAsync(sl.lv.f[MG3D_U], 0, sl.lv.elems * sizeof(double), s); /* mg_3d.h:1258 */
+            slab_smooth_residual(D, R, l, 0, 2); /* :1282 + :1294 */
+            if (l - 1 >= ld) {
+                SlabLevel &sc = SL(D, R, l - 1);
+                /* owned coarse planes, plus the physical boundary planes at the ends of the domain */
+                k_restrict(sl.lv.g, sl.lv.f[MG3D_R], sc.lv.g, sc.lv.f[MG3D_D], s, sc.own_lo, sc.own_hi); /* :1310 */
+            } else {
+                Level &lc = R.coarse->lv[ld - 1];
+                int lo = sl.glo / 2, hi = sl.ghi / 2;
+                if (R.rank == 0)
+                    lo = 0;
+                if (R.rank == D->P - 1)
+                    hi = lc.g.N;
+                k_restrict(sl.lv.g, sl.lv.f[MG3D_R], lc.g, lc.f[MG3D_D], s, lo, hi);
+            }
+        }
+        if (l - 1 >= ld)
+            CHK(exchange_halo(D, MG3D_D, l - 1));
+        else
+            CHK(allgather_coarse_rhs(D));
+    }
+    /* ---- replicated levels: the ordinary V-cycle from level ld-1 (its guess zeroed first, :1258) */
+    for (auto &R : D->rs) {
+        Level &lc = R.coarse->lv[ld - 1];
+        (void)hipMemsetAsync(lc.f[MG3D_U], 0, lc.elems * sizeof(double), s);
+        if (ld - 1 == 0)
+            CHK(mg3d_coarse_solve(R.coarse));
+        else
+            CHK(mg3d_enqueue_vcycle(R.coarse, ld - 1, R.coarse->sumsq_slots - 1));
+    }
+    /* ---- up */
+    for (int l = ld; l < L; l++) {
+        for (auto &R : D->rs) {
+            SlabLevel &sl = SL(D, R, l);
+            if (l - 1 >= ld) {
+                SlabLevel &sc = SL(D, R, l - 1);
+                k_prolong(sc.lv.g, sc.lv.f[MG3D_U], sl.lv.g, sl.lv.f[MG3D_U], s, sl.own_lo, sl.own_hi); /* :1331 */
+            } else {
+                Level &lc = R.coarse->lv[ld - 1];
+                k_prolong(lc.g, lc.f[MG3D_U], sl.lv.g, sl.lv.f[MG3D_U], s, sl.own_lo, sl.own_hi);
+            }
+        }
+        CHK(exchange_halo(D, MG3D_U, l));
+        for (auto &R : D->rs)
+            slab_smooth_residual(D, R, l, 1, l == L - 1 ? 1 : 0); /* :1341 (+ :1354 at the top level) */
+    }
+    /* the next cycle (or a download of halo-inclusive data) starts from exact halos */
+    CHK(exchange_halo(D, MG3D_U, L - 1));
+    CHK(reduce_norm(D, slot));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(MG3D_ERR_HIP, "mg3d_dist_vcycles: kernel launch failed: %s", hipGetErrorString(e));
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_dist_vcycles(mg3d_dist *D, int count, double *norms)
+{
+    if (!D || count < 0)
+        return fail(MG3D_ERR_ARG, "mg3d_dist_vcycles: bad arguments");
+    for (int done = 0; done < count;) {
+        const int nb = (count - done < D->norm_slots) ? count - done : D->norm_slots;
+        for (int c = 0; c < nb; c++)
+            CHK(dist_enqueue_vcycle(D, c));
+        HIPCHK(hipMemcpyAsync(D->h_norms, D->d_norms, nb * sizeof(double), hipMemcpyDeviceToHost, D->stream));
+        HIPCHK(hipStreamSynchronize(D->stream));
+        if (norms)
+            for (int c = 0; c < nb; c++)
+                norms[done + c] = sqrt(D->h_norms[c]);
+        done += nb;
+    }
+    return MG3D_OK;
+}

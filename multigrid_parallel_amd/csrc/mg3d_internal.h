@@ -44,8 +44,11 @@ void k_smooth_color(const Geom &g, double *v, const double *d, double hSq, int c
 void k_residual(const Geom &g, const double *v, const double *d, double invHsq, double *res, double *partials,
                 double *sumsq_out, hipStream_t s);
 void k_sumsq(const Geom &g, const double *a, double *partials, double *sumsq_out, hipStream_t s);
-void k_restrict(const Geom &gf, const double *r, const Geom &gc, double *dc, hipStream_t s);
-void k_prolong(const Geom &gc, const double *ec, const Geom &gf, double *ef, hipStream_t s);
+/* ic_lo/ic_hi, if_lo/if_hi: local plane range to produce; -1 = every local plane that is not a slab halo */
+void k_restrict(const Geom &gf, const double *r, const Geom &gc, double *dc, hipStream_t s, int ic_lo = -1,
+                int ic_hi = -1);
+void k_prolong(const Geom &gc, const double *ec, const Geom &gf, double *ef, hipStream_t s, int if_lo = -1,
+               int if_hi = -1);
 /* folds np per-block partial sums, in a fixed order, into *out */
 void k_fold(const double *partials, int np, double *out, hipStream_t s);
 /* fused sweep (mg3d_sweep.hip): S colour passes starting with colour c1 (1 red, 0 black) from vin into
@@ -53,7 +56,8 @@ void k_fold(const double *partials, int np, double *out, hipStream_t s);
  * receives it on the interior, partials (may be NULL) one sum of diff^2 per block.  Returns the number
  * of partials written (>= 0) or -1 when the (S, residual) shape has no instantiation. */
 int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
-            int max_partials, double h, int S, int c1, bool residual, hipStream_t s);
+            int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo = 0,
+            int acc_hi = -1 /* local planes entering the norm; default all */);
 /* b and x are level-0 grids in the padded layout g0; work holds 2n doubles */
 void k_lu_solve(const LuBand &lu, const Geom &g0, const double *b_pad, double *x_pad, double *work, hipStream_t s);
 

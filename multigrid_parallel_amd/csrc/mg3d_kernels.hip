@@ -216,12 +216,12 @@ __global__ void __launch_bounds__(256) restrict_kernel(Geom gf, const double *__
     dc[gidx(gc, ic, jc, kc)] = val;
 }
 
-void k_restrict(const Geom &gf, const double *r, const Geom &gc, double *dc, hipStream_t s)
+void k_restrict(const Geom &gf, const double *r, const Geom &gc, double *dc, hipStream_t s, int ic_lo, int ic_hi)
 {
     /* local coarse planes written: physical boundary planes and owned planes; a
      * halo plane (local 0 / ni-1 that is not a physical boundary) is the neighbour's */
-    const int lo = (gc.ig0 == 0) ? 0 : 1;
-    const int hi = (gc.ig0 + gc.ni == gc.N) ? gc.ni : gc.ni - 1;
+    const int lo = ic_lo >= 0 ? ic_lo : ((gc.ig0 == 0) ? 0 : 1);
+    const int hi = ic_hi >= 0 ? ic_hi : ((gc.ig0 + gc.ni == gc.N) ? gc.ni : gc.ni - 1);
     if (hi <= lo)
         return;
     dim3 grid((gc.nk + 63) / 64, (gc.nj + 3) / 4, hi - lo);
@@ -295,10 +295,10 @@ __global__ void __launch_bounds__(256) prolong_kernel(Geom gc, const double *__r
     ef[p] += t;
 }
 
-void k_prolong(const Geom &gc, const double *ec, const Geom &gf, double *ef, hipStream_t s)
+void k_prolong(const Geom &gc, const double *ec, const Geom &gf, double *ef, hipStream_t s, int if_lo, int if_hi)
 {
-    const int lo = (gf.ig0 == 0) ? 0 : 1;
-    const int hi = (gf.ig0 + gf.ni == gf.N) ? gf.ni : gf.ni - 1;
+    const int lo = if_lo >= 0 ? if_lo : ((gf.ig0 == 0) ? 0 : 1);
+    const int hi = if_hi >= 0 ? if_hi : ((gf.ig0 + gf.ni == gf.N) ? gf.ni : gf.ni - 1);
     if (hi <= lo)
         return;
     dim3 grid((gf.nk + 63) / 64, (gf.nj + 3) / 4, hi - lo);

@@ -56,6 +56,7 @@ struct SweepArgs {
     int c1;         /* colour of the first pass: 1 red, 0 black */
     int ntj, ntk;   /* tiles in j, k */
     int CI, nci;    /* planes per i-chunk, number of chunks */
+    int acc_lo, acc_hi; /* local planes whose diff^2 enter the norm (owned planes of a slab) */
     int xcd_remap;  /* 1: renumber blocks so that consecutive tiles share an XCD (and its L2) */
 };
 
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                         const double diff = dd - a.invHsq * (sum - 6 * nw[s]); /* mg_3d.h:819-821 */
                         diffs[0] = diff;
                         const int q = i - s;
-                        if (upd && row_own[rr] && pair_own && q >= i_out0 && q < i_out1)
+                        if (upd && row_own[rr] && pair_own && q >= i_out0 && q < i_out1 && q >= a.acc_lo && q < a.acc_hi)
                             acc += diff * diff;
                     }
                 } else {
@@ -264,7 +265,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                     nw[s] = center;
                     diffs[S > 0 ? 1 : s - 1] = diff;
                     const int q = i - s;
-                    if (upd && row_own[rr] && pair_own && q >= i_out0 && q < i_out1)
+                    if (upd && row_own[rr] && pair_own && q >= i_out0 && q < i_out1 && q >= a.acc_lo && q < a.acc_hi)
                         acc += diff * diff;
                 }
             }
@@ -430,9 +431,11 @@ template <> int dispatch<0, true>(SweepArgs &a, SweepCfg c, int max_partials, hi
 /* S colour passes starting with colour c1, optional residual.  Returns the number of
  * partial sums written (0 when no norm was requested), -1 if the shape is unsupported. */
 int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
-            int max_partials, double h, int S, int c1, bool residual, hipStream_t s)
+            int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo, int acc_hi)
 {
     SweepArgs a;
+    a.acc_lo = acc_lo;
+    a.acc_hi = acc_hi < 0 ? g.ni : acc_hi;
     a.g = g;
     a.vin = vin;
     a.d = d;
