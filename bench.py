@@ -93,7 +93,7 @@ def run_cpu_baseline(args):
     cores = host_cores()
     env.update(OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close", OMP_PLACES="cores")
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", "--coarse", str(args.coarse), "--levels",
-           str(args.levels), "--nu", str(args.nu), "--cpu-cycles", str(args.cpu_cycles)]
+           str(args.levels), "--smooth-iters", str(args.nu), "--cpu-cycles", str(args.cpu_cycles)]
     if args.cpu_port:
         cmd.append("--cpu-port")
     try:
@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--coarse", type=int, default=9)
     ap.add_argument("--levels", type=int, default=7)
-    ap.add_argument("--nu", type=int, default=2)
+    ap.add_argument("--smooth-iters", dest="nu", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cycles", type=int, default=8)
     ap.add_argument("--cpu-port", action="store_true", help="time oracle/ (port) even if oracle/_ref exists")
@@ -132,40 +132,79 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible (the product has no CPU path)")
+    if "MG3D_BENCH_DEVICE" in os.environ:  # rehearsal of several ranks on one GPU (RCCL permitting)
+        local_rank = int(os.environ["MG3D_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MG3D_BENCH_TORCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import multigrid_parallel_amd as M
     from multigrid_parallel_amd.binding import MG3D_U
 
     c, L, nu = args.coarse, args.levels, args.nu
     N = (c - 1) * (1 << (L - 1)) + 1
+
+    def barrier(obj):
+        if world > 1:
+            dist.barrier()
+        obj.sync()
+        torch.cuda.synchronize()
+
     if world > 1:
-        sys.exit("bench.py: multi-GPU slab path not wired into this build yet")
+        # i-slab decomposition: one rank per GPU, the library's own RCCL communicator for the plane
+        # exchanges (unique id distributed through torch.distributed), strong scaling of the same problem
+        uid = [M.DistSolver.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        solver = M.DistSolver(c, L, nu, rank=rank, nranks=world, unique_id=uid[0], device=local_rank)
+        init = solver.setup_test_problem()
+        solver.vcycles(args.warmup)
+        barrier(solver)
+        t0 = time.perf_counter()
+        norms = solver.vcycles(args.steps)
+        barrier(solver)
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        if rank == 0:
+            alg = algorithmic_bytes_per_cycle(c, L, nu)
+            per_step = elapsed / args.steps
+            print(json.dumps({
+                "metric": "V-cycles/sec, 513^3 ('512^3') Poisson, V(2,2), fp64" if (c, L, nu) == (9, 7, 2)
+                else f"V-cycles/sec, {N}^3 Poisson, V({nu},{nu}), fp64",
+                "value": args.steps / elapsed, "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"{N}^3 Poisson (args {c} {L} {nu}), Dirichlet x^2-2y^2+z^2, V({nu},{nu}), "
+                                       f"device-resident, test_mg_3d.c problem", "coarse_pts": c, "levels": L,
+                           "smooth_iters": nu, "parallelism": f"{world} GPUs, i-slabs, halo {solver.halo} planes, "
+                                                              f"levels >= {solver.first_level} distributed, RCCL send/recv"},
+                "vcycle_algorithmic_gb": alg / 1e9, "vcycle_algorithmic_gbs": alg / per_step / 1e9,
+                "vcycle_frac_of_hbm_peak": alg / per_step / 1e9 / (HBM_PEAK_GBS * world),
+                "first_norm": float(norms[0]), "last_norm": float(norms[-1]), "initial_rhs_norm": init,
+                "roofline": None, "cpu_baseline": None}))
+        solver.close()
+        dist.destroy_process_group()
+        return
+
     solver = M.Solver(c, L, nu)
     solver.setup_test_problem()
     init = solver.get_initial_residual()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        solver.sync()
-        torch.cuda.synchronize()
-
     solver.vcycles(args.warmup)
     solver.timing_reset()
     solver.timing_enable(1 if args.breakdown else 2)  # event pairs around the finest-level stages only; no host stall
-    barrier()
+    barrier(solver)
     t0 = time.perf_counter()
     norms = solver.vcycles(args.steps)
-    barrier()
+    barrier(solver)
     elapsed = time.perf_counter() - t0
     solver.timing_enable(0)
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     tm = solver.timing()
     kt = solver.kernel_times()
@@ -233,8 +272,6 @@ def main():
             solver.finalize()
             line["cpu_baseline"] = run_cpu_baseline(args)
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

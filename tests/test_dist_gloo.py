@@ -1,0 +1,185 @@
+"""World-size-2 (and 3) run of the i-slab V-cycle SCHEDULE on CPU: real processes, torch.distributed `gloo`
+send/recv for the halo planes, broadcast for the replicated right-hand side, all_gather for the norm.
+
+What is under test is the host logic the multi-GPU path rests on: the partition (`mg3d_slab_*` from libmg3d.so,
+pure host arithmetic), the halo depth H = 2*nu+2, and the exchange schedule of csrc/mg3d_dist.hip
+(dist_enqueue_vcycle), mirrored step by step below.  The per-slab arithmetic is the numpy statement of the
+operators (tests/_slab_numpy.py, pinned to the oracle); the replicated levels run the oracle's V-cycle.  The
+assembled solution must equal the single-domain oracle bit for bit.  No GPU, no HIP compute."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import _oracle as O
+import _slab_numpy as S
+import multigrid_parallel_amd as M
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def owned(c, L, P, H, level, r):
+    lo, hi = C.c_int(0), C.c_int(0)
+    assert M.lib().mg3d_slab_owned(c, L, P, H, level, r, C.byref(lo), C.byref(hi)) == 0
+    return lo.value, hi.value
+
+
+class Slab:
+    def __init__(self, c, L, P, H, level, r):
+        self.N = (c - 1) * (1 << level) + 1
+        self.glo, self.ghi = owned(c, L, P, H, level, r)
+        self.h_lo = H if r > 0 else 0
+        self.h_hi = H if r < P - 1 else 0
+        self.ig0 = self.glo - self.h_lo
+        self.ni = self.ghi - self.glo + self.h_lo + self.h_hi
+        self.own_lo, self.own_hi = self.h_lo, self.h_lo + self.ghi - self.glo
+        self.u, self.d, self.r = (np.zeros((self.ni, self.N, self.N)) for _ in range(3))
+
+
+def exchange(field, sl, r, P, H):
+    """exchange_halo of mg3d_dist.hip: last/first H owned planes to the upper/lower neighbour's halo."""
+    a = getattr(sl, field)
+    reqs, bufs = [], []
+    if r + 1 < P:
+        reqs.append(dist.isend(torch.from_numpy(a[sl.own_hi - H:sl.own_hi].copy()), r + 1))
+        up = torch.empty((H, sl.N, sl.N), dtype=torch.float64)
+        reqs.append(dist.irecv(up, r + 1))
+        bufs.append((up, slice(sl.own_hi, sl.own_hi + H)))
+    if r > 0:
+        reqs.append(dist.isend(torch.from_numpy(a[sl.own_lo:sl.own_lo + H].copy()), r - 1))
+        dn = torch.empty((H, sl.N, sl.N), dtype=torch.float64)
+        reqs.append(dist.irecv(dn, r - 1))
+        bufs.append((dn, slice(sl.own_lo - H, sl.own_lo)))
+    for q in reqs:
+        q.wait()
+    for t, s in bufs:
+        a[s] = t.numpy()
+
+
+def worker(r, P, port, c, L, nu, cycles, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=r, world_size=P)
+    lib = M.lib()
+    H = lib.mg3d_slab_halo(nu)
+    ld = lib.mg3d_slab_first_level(c, L, P, H)
+    Nf = (c - 1) * (1 << (L - 1)) + 1
+    hs = [1.0 / (Nf - 1) * (1 << (L - 1 - l)) for l in range(L)]
+    lv = {l: Slab(c, L, P, H, l, r) for l in range(ld, L)}
+    # replicated hierarchy 0..ld-1 (oracle layout) + LU with the reference's coarse spacing (mg_3d.h:287)
+    Hc = O.Hierarchy(c, ld)
+    n0 = c ** 3
+    LU = np.zeros(n0 * n0)
+    O.lib().orc_coarse_matrix(O.P(LU), c, hs[0])
+    O.lib().orc_lu_factor(O.P(LU), n0)
+    O.lib().orc_set_threads(1)
+    # test_mg_3d.c problem on the full grid, each rank keeps its slab
+    full = np.zeros(Nf ** 3)
+    O.lib().orc_fill_boundary(O.P(full), Nf, hs[L - 1])
+    f3 = full.reshape(Nf, Nf, Nf)
+    top = lv[L - 1]
+    top.u[:] = f3[top.ig0:top.ig0 + top.ni]
+    top.d[:] = f3[top.ig0:top.ig0 + top.ni]
+    norms = []
+    for _ in range(cycles):
+        for l in range(L - 1, ld - 1, -1):  # ---- down
+            sl = lv[l]
+            if l < L - 1:
+                sl.u[:] = 0.0
+            S.smooth(sl.u, sl.d, hs[l], nu, False, sl.ig0, sl.N)
+            S.residual(sl.u, sl.d, hs[l], sl.r, sl.ig0, sl.N)
+            if l - 1 >= ld:
+                sc = lv[l - 1]
+                S.restrict_planes(sl.r, sl.ig0, sl.N, sc.d, sc.ig0, sc.N, sc.own_lo, sc.own_hi)
+                exchange("d", sc, r, P, H)
+            else:
+                Nc = Hc.N[ld - 1]
+                dc = Hc.d[ld - 1].reshape(Nc, Nc, Nc)
+                rng = []
+                for q in range(P):
+                    flo, fhi = owned(c, L, P, H, ld, q)
+                    rng.append((0 if q == 0 else flo // 2, Nc if q == P - 1 else fhi // 2))
+                S.restrict_planes(sl.r, sl.ig0, sl.N, dc, 0, Nc, rng[r][0], rng[r][1])
+                for q in range(P):  # allgather_coarse_rhs: one broadcast per owner
+                    t = torch.from_numpy(dc[rng[q][0]:rng[q][1]].copy())
+                    dist.broadcast(t, src=q)
+                    dc[rng[q][0]:rng[q][1]] = t.numpy()
+        # ---- replicated levels, identical on every rank
+        Hc.u[ld - 1][:] = 0.0
+        O.lib().orc_vcycle(Hc.ptrs(Hc.u), Hc.ptrs(Hc.d), Hc.ptrs(Hc.r), hs[ld - 1], ld - 1, L, nu, Hc.N[ld - 1], O.P(LU))
+        for l in range(ld, L):  # ---- up
+            sl = lv[l]
+            if l - 1 >= ld:
+                sc = lv[l - 1]
+                S.prolong_planes(sc.u, sc.ig0, sc.N, sl.u, sl.ig0, sl.N, sl.own_lo, sl.own_hi)
+            else:
+                Nc = Hc.N[ld - 1]
+                S.prolong_planes(Hc.u[ld - 1].reshape(Nc, Nc, Nc), 0, Nc, sl.u, sl.ig0, sl.N, sl.own_lo, sl.own_hi)
+            exchange("u", sl, r, P, H)
+            S.smooth(sl.u, sl.d, hs[l], nu, True, sl.ig0, sl.N)
+        ss = S.residual(top.u, top.d, hs[L - 1], None, top.ig0, top.N, top.own_lo, top.own_hi)
+        exchange("u", top, r, P, H)
+        parts = [torch.zeros(1, dtype=torch.float64) for _ in range(P)]
+        dist.all_gather(parts, torch.tensor([ss], dtype=torch.float64))
+        norms.append(float(np.sqrt(sum(float(p) for p in parts))))
+    # assemble the owned planes on rank 0
+    mine = torch.from_numpy(top.u[top.own_lo:top.own_hi].copy())
+    if r == 0:
+        u = np.zeros((Nf, Nf, Nf))
+        u[top.glo:top.ghi] = mine.numpy()
+        for q in range(1, P):
+            lo, hi = owned(c, L, P, H, L - 1, q)
+            t = torch.empty((hi - lo, Nf, Nf), dtype=torch.float64)
+            dist.recv(t, q)
+            u[lo:hi] = t.numpy()
+        np.savez(out_path, u=u.reshape(-1), norms=np.array(norms))
+    else:
+        dist.send(mine, 0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("c,L,nu,P", [(5, 5, 2, 2), (5, 5, 1, 2), (3, 6, 2, 3)])
+def test_slab_schedule_over_gloo(tmp_path, c, L, nu, P):
+    cycles = 3
+    out = str(tmp_path / "res.npz")
+    mp.spawn(worker, args=(P, free_port(), c, L, nu, cycles, out), nprocs=P, join=True)
+    got = np.load(out)
+    O.lib().orc_set_threads(1)
+    want_norms, want_u, _, _ = O.run_problem(c, L, nu, cycles)
+    assert np.array_equal(got["u"], want_u)
+    np.testing.assert_allclose(got["norms"], want_norms, rtol=1e-12)
+
+
+def test_partition_properties():
+    """Cuts are nested (coarse plane ic and fine plane 2*ic share an owner), cover the level, and leave every rank
+    at least a halo's worth of planes."""
+    lib = M.lib()
+    for (c, L, nu, P) in [(9, 7, 2, 8), (9, 7, 2, 4), (9, 7, 2, 2), (5, 6, 3, 3), (9, 8, 2, 8), (3, 7, 1, 5)]:
+        H = lib.mg3d_slab_halo(nu)
+        assert H == 2 * nu + 2
+        ld = lib.mg3d_slab_first_level(c, L, P, H)
+        assert 1 <= ld < L
+        for l in range(ld, L):
+            N = (c - 1) * (1 << l) + 1
+            prev = 0
+            for r in range(P):
+                lo, hi = owned(c, L, P, H, l, r)
+                assert lo == prev and hi - lo >= H
+                prev = hi
+                if l > ld:
+                    clo, chi = owned(c, L, P, H, l - 1, r)
+                    assert lo == 2 * clo and (hi == 2 * chi or (r == P - 1 and hi == N))
+                else:
+                    assert lo % 2 == 0
+            assert prev == N
+    assert lib.mg3d_slab_first_level(9, 7, 8, 6) == 3  # 513^3 on 8 GPUs: 65^3 and up distributed
+    assert owned(9, 7, 8, 6, 6, 3) == (192, 256)
