@@ -11,6 +11,8 @@
  */
 #include "mg3d_internal.h"
 
+#include <stdlib.h>
+
 #define WAVE 64
 
 __device__ __forceinline__ long long gidx(const Geom &g, int i, int j, int k)
@@ -295,12 +297,97 @@ __global__ void __launch_bounds__(256) prolong_kernel(Geom gc, const double *__r
     ef[p] += t;
 }
 
+/* Cell-based form used by the V-cycle: a thread owns one coarse cell (jc, m) -- the 2 x 2 fine points
+ * (2jc, 2jc+1) x (2m, 2m+1) of every fine plane -- and marches along i.  The eight coarse corners
+ * E[a][b][c] = ec(il+a, jc+b, m+c) of the current cell stay in registers and are reused by the two fine
+ * planes that share them; fine data moves as 16-byte k-pairs.  Same parent order as prolong_kernel. */
+__global__ void __launch_bounds__(256) prolong_cell_kernel(Geom gc, const double *__restrict__ ec, Geom gf,
+                                                           double *__restrict__ ef, int if_lo, int if_hi, int chunk)
+{
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    const int jc = blockIdx.y * 4 + threadIdx.y;
+    const int k0 = 2 * m, j0 = 2 * jc;
+    if (k0 >= gf.nk || j0 >= gf.nj)
+        return;
+    const int i_beg = if_lo + blockIdx.z * chunk;
+    const int i_end = min(if_hi, i_beg + chunk);
+    const bool row1 = j0 + 1 < gf.nj;
+    const int m1 = min(m + 1, gc.nk - 1), jc1 = min(jc + 1, gc.nj - 1);
+    const long long c00 = (long long)gc.pitch * jc + m, c01 = (long long)gc.pitch * jc + m1;
+    const long long c10 = (long long)gc.pitch * jc1 + m, c11 = (long long)gc.pitch * jc1 + m1;
+    double E0[2][2], E1[2][2]; /* coarse planes `have` and `have + 1`, [b][c] */
+    int have = -0x40000000;
+    auto load = [&](int il, double(&E)[2][2]) {
+        const double *pl = ec + gc.plane * min(max(il, 0), gc.ni - 1);
+        E[0][0] = pl[c00];
+        E[0][1] = pl[c01];
+        E[1][0] = pl[c10];
+        E[1][1] = pl[c11];
+    };
+    for (int i = i_beg; i < i_end; i++) {
+        const int ig = gf.ig0 + i, oi = ig & 1;
+        const int il = (ig - oi) / 2 - gc.ig0;
+        if (have != il) {
+            if (have + 1 == il) {
+                E0[0][0] = E1[0][0];
+                E0[0][1] = E1[0][1];
+                E0[1][0] = E1[1][0];
+                E0[1][1] = E1[1][1];
+            } else {
+                load(il, E0);
+            }
+            load(il + 1, E1);
+            have = il;
+        }
+        double t00, t01, t10, t11; /* [row parity][col parity] */
+        if (!oi) {
+            t00 = E0[0][0];
+            t01 = (E0[0][0] + E0[0][1]) * 0.5;
+            t10 = (E0[0][0] + E0[1][0]) * 0.5;
+            t11 = (((E0[0][0] + E0[1][0]) + E0[0][1]) + E0[1][1]) * 0.25; /* i even: (jl,kl)(jl+1,kl)(jl,kl+1)(jl+1,kl+1) */
+        } else {
+            t00 = (E0[0][0] + E1[0][0]) * 0.5;
+            t01 = (((E0[0][0] + E1[0][0]) + E0[0][1]) + E1[0][1]) * 0.25; /* j even: (il,kl)(il+1,kl)(il,kl+1)(il+1,kl+1) */
+            t10 = (((E0[0][0] + E0[1][0]) + E1[0][0]) + E1[1][0]) * 0.25; /* k even: (il,jl)(il,jl+1)(il+1,jl)(il+1,jl+1) */
+            double t = E0[0][0] + E0[0][1];
+            t = t + E0[1][0];
+            t = t + E0[1][1];
+            t = t + E1[0][0];
+            t = t + E1[0][1];
+            t = t + E1[1][0];
+            t = t + E1[1][1];
+            t11 = t * 0.125;
+        }
+        double *row = ef + gf.plane * i + (long long)gf.pitch * j0 + k0;
+        double2 a = *reinterpret_cast<double2 *>(row);
+        a.x += t00;
+        a.y += t01;
+        *reinterpret_cast<double2 *>(row) = a;
+        if (row1) {
+            double2 b = *reinterpret_cast<double2 *>(row + gf.pitch);
+            b.x += t10;
+            b.y += t11;
+            *reinterpret_cast<double2 *>(row + gf.pitch) = b;
+        }
+    }
+}
+
 void k_prolong(const Geom &gc, const double *ec, const Geom &gf, double *ef, hipStream_t s, int if_lo, int if_hi)
 {
     const int lo = if_lo >= 0 ? if_lo : ((gf.ig0 == 0) ? 0 : 1);
     const int hi = if_hi >= 0 ? if_hi : ((gf.ig0 + gf.ni == gf.N) ? gf.ni : gf.ni - 1);
     if (hi <= lo)
         return;
+    static const bool simple = getenv("MG3D_SIMPLE_PROLONG") && getenv("MG3D_SIMPLE_PROLONG")[0] == '1';
+    if (!simple && gf.nk == 2 * gc.nk - 1 && gf.nj == 2 * gc.nj - 1) {
+        const int gx = ((gf.nk + 1) / 2 + 63) / 64, gy = ((gf.nj + 1) / 2 + 3) / 4;
+        int chunk = 64; /* a few hundred to a few thousand blocks, like the sweep */
+        while (chunk > 4 && (long long)gx * gy * ((hi - lo + chunk - 1) / chunk) < 2048)
+            chunk /= 2;
+        dim3 grid(gx, gy, (hi - lo + chunk - 1) / chunk);
+        hipLaunchKernelGGL(prolong_cell_kernel, grid, dim3(64, 4, 1), 0, s, gc, ec, gf, ef, lo, hi, chunk);
+        return;
+    }
     dim3 grid((gf.nk + 63) / 64, (gf.nj + 3) / 4, hi - lo);
     hipLaunchKernelGGL(prolong_kernel, grid, dim3(64, 4, 1), 0, s, gc, ec, gf, ef, lo, hi);
 }

@@ -359,7 +359,8 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
      * 500-1000 blocks (513^3: CI 64-128, 257^3: 16, 129^3: 8, <= 65^3: 2-4). */
     auto blocks = [&](int ci) { return (long long)a.ntj * a.ntk * ((g.ni + ci - 1) / ci); };
     int CI = 8;
-    while (CI < 128 && blocks(CI) > 800)
+    const long long most = Sh::ST <= 2 ? 1600 : 800; /* a short pipeline tolerates shorter chunks */
+    while (CI < 128 && blocks(CI) > most)
         CI *= 2;
     while (CI > 2 && blocks(CI) < 100)
         CI /= 2;
@@ -424,7 +425,7 @@ template <> int dispatch<2, false>(SweepArgs &a, SweepCfg c, int max_partials, h
 }
 template <> int dispatch<0, true>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
-    TRY(0, true, 4, 8, 1) TRY(0, true, 8, 4, 2) TRY(0, true, 6, 8, 1)
+    TRY(0, true, 4, 8, 1) TRY(0, true, 8, 4, 2) TRY(0, true, 4, 8, 2) TRY(0, true, 4, 8, 3) TRY(0, true, 2, 8, 4)
     return -1;
 }
 

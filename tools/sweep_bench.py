@@ -38,7 +38,8 @@ cases = {
     "S4": (lambda: s.smooth(lev, 0, 2), 6 * n * 8, ["8,4,1", "8,4,2", "6,4,2", "4,8,1"]),
     "S2RES": (lambda: s.smooth_residual(lev, 0, 1, True, False), (3 + 3) * n * 8, ["4,8,1", "8,4,2", "6,4,2"]),
     "S2": (lambda: s.smooth(lev, 0, 1), 3 * n * 8, ["6,8,1", "8,4,2", "4,8,1"]),
-    "S0RES": (lambda: s.residual(lev, True, False), 3 * n * 8, ["4,8,1", "8,4,2", "6,8,1"]),
+    "S0RES": (lambda: s.residual(lev, True, False), 3 * n * 8, ["4,8,1", "8,4,2", "4,8,2", "4,8,3", "2,8,4"]),
+    "S0NORM": (lambda: s.residual(lev, False, False), 2 * n * 8, ["4,8,1", "8,4,2", "4,8,2", "4,8,3", "2,8,4"]),
 }
 only = os.environ.get("ONLY")
 cfg_override = os.environ.get("CFGS")
@@ -47,9 +48,9 @@ for name, (fn, alg, cfgs) in cases.items():
         continue
     for cfg in (cfg_override.split(";") if cfg_override else cfgs):
         os.environ["MG3D_SWEEP_CFG"] = cfg
-        for ci in os.environ.get("CIS", "64").split(","):
+        for ci in os.environ.get("CIS", "0").split(","):
             os.environ["MG3D_SWEEP_CI"] = ci
-            for xcd in os.environ.get("XCDS", "1").split(","):
+            for xcd in os.environ.get("XCDS", "0").split(","):
                 os.environ["MG3D_XCD"] = xcd
                 t = timeit(fn)
                 print(f"{name:6s} cfg {cfg:6s} CI {ci:>3s} xcd {xcd}: {t * 1e3:8.3f} ms   algorithmic {alg / t / 1e9:8.1f} GB/s", flush=True)
