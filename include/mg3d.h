@@ -56,6 +56,10 @@ int mg3d_ctx_num_levels(const mg3d_ctx *ctx);
 int mg3d_ctx_level_n(const mg3d_ctx *ctx, int level); /* points per side, mg_3d.h:41 */
 double mg3d_ctx_level_h(const mg3d_ctx *ctx, int level);
 int mg3d_ctx_set_smooth_iters(mg3d_ctx *ctx, int iters);
+/* keep != 0: every V-cycle materialises the residual arrays r[level] as the reference does (mg_3d.h:1294).
+ * Default 0: the residual is restricted into the coarse right-hand side on the fly and r is not written --
+ * u, d and the returned norms are identical either way.  mg3d_host_vcycle always keeps r. */
+int mg3d_ctx_set_keep_residual(mg3d_ctx *ctx, int keep);
 
 /* Coarsest operator.  mg3d_ctx_build_coarse = constructCoarseMatrixA +
  * convertToLU_InPlace as SolverGetDetails does (mg_3d.h:282-289), with the
@@ -133,6 +137,7 @@ int mg3d_dist_destroy(mg3d_dist *d);
 int mg3d_dist_first_level(const mg3d_dist *d); /* lowest distributed level */
 int mg3d_dist_halo(const mg3d_dist *d);        /* halo planes per side */
 int mg3d_dist_build_coarse(mg3d_dist *d, double h_coarse);
+int mg3d_dist_set_keep_residual(mg3d_dist *d, int keep); /* as mg3d_ctx_set_keep_residual */
 int mg3d_dist_upload(mg3d_dist *d, int field, int level, const double *host_full);
 int mg3d_dist_download(mg3d_dist *d, int field, int level, double *host_full);
 int mg3d_dist_vcycles(mg3d_dist *d, int count, double *norms);

@@ -37,6 +37,7 @@ SIGNATURES = {
     "mg3d_ctx_level_n": (C.c_int, [C.c_void_p, C.c_int]),
     "mg3d_ctx_level_h": (C.c_double, [C.c_void_p, C.c_int]),
     "mg3d_ctx_set_smooth_iters": (C.c_int, [C.c_void_p, C.c_int]),
+    "mg3d_ctx_set_keep_residual": (C.c_int, [C.c_void_p, C.c_int]),
     "mg3d_ctx_build_coarse": (C.c_int, [C.c_void_p, C.c_double]),
     "mg3d_ctx_set_lu": (C.c_int, [C.c_void_p, dp]),
     "mg3d_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
@@ -65,6 +66,7 @@ SIGNATURES = {
     "mg3d_dist_destroy": (C.c_int, [C.c_void_p]),
     "mg3d_dist_first_level": (C.c_int, [C.c_void_p]),
     "mg3d_dist_halo": (C.c_int, [C.c_void_p]),
+    "mg3d_dist_set_keep_residual": (C.c_int, [C.c_void_p, C.c_int]),
     "mg3d_dist_build_coarse": (C.c_int, [C.c_void_p, C.c_double]),
     "mg3d_dist_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
     "mg3d_dist_download": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
@@ -158,6 +160,9 @@ class Solver:
 
     def __exit__(self, *a):
         self.finalize()
+
+    def set_keep_residual(self, keep=True):
+        check(self.L.mg3d_ctx_set_keep_residual(self._h, int(keep)))
 
     # -- geometry
     def level_n(self, level):
@@ -328,6 +333,9 @@ class DistSolver:
 
     def level_n(self, level):
         return (self.c - 1) * (1 << level) + 1
+
+    def set_keep_residual(self, keep=True):
+        check(self.L.mg3d_dist_set_keep_residual(self._h, int(keep)))
 
     def setup_test_problem(self):
         """test_mg_3d.c:11-29 on the full grid; every rank takes its slab."""

@@ -32,6 +32,7 @@ struct mg3d_ctx {
     double *sumsq;    /* device slots for squared norms */
     int sumsq_slots;
     double *h_sumsq;  /* pinned mirror */
+    bool keep_r; /* materialise r on every level (reference-visible array) instead of restricting it on the fly */
     bool fused; /* fused sweep kernel (default) or one launch per colour pass (MG3D_NO_FUSE=1) */
     int timing; /* 0 off, 1 every level, 2 finest level only */
     std::vector<StageTimer> timers; /* [L][MG3D_NUM_STAGES] */

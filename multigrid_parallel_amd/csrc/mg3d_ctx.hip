@@ -200,6 +200,9 @@ static mg3d_ctx *ctx_new(int L, int iters)
     for (auto &l : ctx->lv)
         l.f[0] = l.f[1] = l.f[2] = l.alt = nullptr;
     ctx->fused = true;
+    ctx->keep_r = false;
+    if (const char *e = getenv("MG3D_KEEP_R"))
+        ctx->keep_r = e[0] == '1';
     if (const char *e = getenv("MG3D_NO_FUSE"))
         ctx->fused = !(e[0] == '1');
     return ctx;
@@ -281,6 +284,14 @@ extern "C" double mg3d_ctx_level_h(const mg3d_ctx *ctx, int level)
 {
     return (ctx && level >= 0 && level < ctx->L) ? ctx->lv[level].h : 0.;
 }
+extern "C" int mg3d_ctx_set_keep_residual(mg3d_ctx *ctx, int keep)
+{
+    if (!ctx)
+        return fail(MG3D_ERR_ARG, "mg3d_ctx_set_keep_residual: NULL context");
+    ctx->keep_r = keep != 0;
+    return MG3D_OK;
+}
+
 extern "C" int mg3d_ctx_set_smooth_iters(mg3d_ctx *ctx, int iters)
 {
     if (!ctx || iters < 0)
@@ -473,8 +484,11 @@ static int read_norm(mg3d_ctx *ctx, int slot, double *norm)
  * Fused path: chunks of 4 (or 2) passes per launch, each launch reading u and writing the
  * alternate buffer; the residual rides on the last launch.  want_res: 0 none, 1 norm only,
  * 2 store r (+ norm).  The squared norm goes to sumsq[slot]. */
-static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters, int want_res, int slot)
+static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters, int want_res, int slot,
+                                    Level *coarse = nullptr)
 {
+    /* coarse != NULL (with want_res != 0): the residual is restricted on the fly into the interior of
+     * coarse->d and never stored; the caller adds the face injection (k_restrict, faces_only) */
     Level &l = ctx->lv[level];
     hipStream_t s = ctx->stream;
     const int c1 = post ? 0 : 1; /* pre: red first (mg_3d.h:657); post: black first (mg_3d.h:728) */
@@ -488,12 +502,15 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
              * window leaves too few registers for a tile with a useful interior: measured 1.9 ms fused
              * against 0.85 + 0.76 ms split on a 513^3 level) */
             const bool res = last && want_res != 0 && S != 4;
+            const bool rst = res && coarse != nullptr;
             int np;
             {
                 StageScope kt(ctx, level, S == 4 ? MG3D_K_SWEEP4 : S == 2 ? (res ? MG3D_K_SWEEP2_RES : MG3D_K_SWEEP2)
                                                                           : MG3D_K_RESIDUAL, true);
-                np = k_sweep(l.g, l.f[MG3D_U], l.f[MG3D_D], l.alt, (res && want_res == 2) ? l.f[MG3D_R] : nullptr,
-                             res ? ctx->partials : nullptr, MG3D_MAX_PARTIALS, l.h, S, c1, res, s);
+                np = k_sweep(l.g, l.f[MG3D_U], l.f[MG3D_D], l.alt,
+                             (res && want_res == 2 && !rst) ? l.f[MG3D_R] : nullptr, res ? ctx->partials : nullptr,
+                             MG3D_MAX_PARTIALS, l.h, S, c1, res, s, 0, -1, rst ? &coarse->g : nullptr,
+                             rst ? coarse->f[MG3D_D] : nullptr);
             }
             if (S > 0) {
                 double *t = l.f[MG3D_U];
@@ -612,7 +629,8 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
         if (ctx->fused) { /* pre-smoother and residual in one pass over the level (:1282 + :1294) */
             {
                 StageScope t(ctx, l, MG3D_ST_SMOOTH1);
-                enqueue_smooth_residual(ctx, l, 0, ctx->iters, 2, ctx->sumsq_slots - 1);
+                enqueue_smooth_residual(ctx, l, 0, ctx->iters, 2, ctx->sumsq_slots - 1,
+                                        ctx->keep_r ? nullptr : &ctx->lv[l - 1]);
             }
             StageScope t(ctx, l, MG3D_ST_RESIDUAL1); /* fused into the launch above: counted, ~0 s */
         } else {
@@ -626,7 +644,9 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
         {
             StageScope t(ctx, l, MG3D_ST_RESTRICT);
             StageScope kt(ctx, l, MG3D_K_RESTRICT, true);
-            k_restrict(lev.g, lev.f[MG3D_R], ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_D], s); /* :1310 */
+            /* :1310; when the interior was restricted on the fly only the face injection (:879-958) is left */
+            k_restrict(lev.g, lev.f[MG3D_R], ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_D], s, -1, -1,
+                       ctx->fused && !ctx->keep_r);
         }
     }
     {
@@ -878,6 +898,7 @@ extern "C" int mg3d_host_vcycle(double **u, double **f, double **res, double h, 
     /* the memset of mg_3d.h:1258 is skipped only on the caller's finest level (q == numLevels-1):
      * emulate by telling the context how many levels the caller's hierarchy has */
     ctx->iters = iters;
+    ctx->keep_r = true; /* the caller owns res[] and may read it */
     ctx->timing = (stage_calls || stage_seconds) ? 1 : 0;
     CHK(mg3d_ctx_set_lu(ctx, LU));
     CHK(mg3d_upload(ctx, MG3D_U, q, u[q]));

@@ -297,6 +297,15 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
 extern "C" int mg3d_dist_first_level(const mg3d_dist *D) { return D ? D->ld : -1; }
 extern "C" int mg3d_dist_halo(const mg3d_dist *D) { return D ? D->H : -1; }
 
+extern "C" int mg3d_dist_set_keep_residual(mg3d_dist *D, int keep)
+{
+    if (!D)
+        return fail(MG3D_ERR_ARG, "mg3d_dist_set_keep_residual: NULL");
+    for (auto &R : D->rs)
+        R.coarse->keep_r = keep != 0;
+    return MG3D_OK;
+}
+
 extern "C" int mg3d_dist_build_coarse(mg3d_dist *D, double h_coarse)
 {
     if (!D)
@@ -474,7 +483,8 @@ static int reduce_norm(mg3d_dist *D, int slot)
 /* ----------------------------------------------------------------------------------------- V-cycle */
 /* iters x two colour passes on a slab level, optional residual (2: store r, 1: norm only into the rank's
  * coarse->sumsq[0] over OWNED planes).  Same launch policy as the single-domain path. */
-static void slab_smooth_residual(mg3d_dist *D, RankState &R, int l, int post, int want_res)
+static void slab_smooth_residual(mg3d_dist *D, RankState &R, int l, int post, int want_res,
+                                 const Geom *gc = nullptr, double *dc = nullptr, int ic_lo = -1, int ic_hi = -1)
 {
     SlabLevel &sl = SL(D, R, l);
     Level &lv = sl.lv;
@@ -487,9 +497,11 @@ static void slab_smooth_residual(mg3d_dist *D, RankState &R, int l, int post, in
         const int S = passes >= 4 ? 4 : passes;
         const bool last = passes - S == 0;
         const bool res = last && want_res != 0 && S != 4;
-        const int np = k_sweep(lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt, (res && want_res == 2) ? lv.f[MG3D_R] : nullptr,
-                               res ? cx->partials : nullptr, MG3D_MAX_PARTIALS, lv.h, S, c1, res, s, sl.own_lo,
-                               sl.own_hi);
+        const bool rst = res && dc != nullptr;
+        const int np = k_sweep(lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt,
+                               (res && want_res == 2 && !rst) ? lv.f[MG3D_R] : nullptr, res ? cx->partials : nullptr,
+                               MG3D_MAX_PARTIALS, lv.h, S, c1, res, s, sl.own_lo, sl.own_hi, rst ? gc : nullptr,
+                               rst ? dc : nullptr, ic_lo, ic_hi);
         if (S > 0) {
             double *t = lv.f[MG3D_U];
             lv.f[MG3D_U] = lv.alt;
@@ -516,20 +528,27 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
             SlabLevel &sl = SL(D, R, l);
             if (l < L - 1)
                 (void)hipMemsetAsync(sl.lv.f[MG3D_U], 0, sl.lv.elems * sizeof(double), s); /* mg_3d.h:1258 */
-            slab_smooth_residual(D, R, l, 0, 2); /* :1282 + :1294 */
+            /* owned coarse planes (plus the physical boundary planes at the ends of the domain) */
+            const Geom *gc;
+            double *dc;
+            int lo, hi;
             if (l - 1 >= ld) {
                 SlabLevel &sc = SL(D, R, l - 1);
-                /* owned coarse planes, plus the physical boundary planes at the ends of the domain */
-                k_restrict(sl.lv.g, sl.lv.f[MG3D_R], sc.lv.g, sc.lv.f[MG3D_D], s, sc.own_lo, sc.own_hi); /* :1310 */
+                gc = &sc.lv.g;
+                dc = sc.lv.f[MG3D_D];
+                lo = sc.own_lo;
+                hi = sc.own_hi;
             } else {
                 Level &lc = R.coarse->lv[ld - 1];
-                int lo = sl.glo / 2, hi = sl.ghi / 2;
-                if (R.rank == 0)
-                    lo = 0;
-                if (R.rank == D->P - 1)
-                    hi = lc.g.N;
-                k_restrict(sl.lv.g, sl.lv.f[MG3D_R], lc.g, lc.f[MG3D_D], s, lo, hi);
+                gc = &lc.g;
+                dc = lc.f[MG3D_D];
+                lo = R.rank == 0 ? 0 : sl.glo / 2;
+                hi = R.rank == D->P - 1 ? lc.g.N : sl.ghi / 2;
             }
+            const bool keep = R.coarse->keep_r;
+            /* :1282 + :1294 + :1310; interior of the coarse rhs on the fly unless r is to be kept */
+            slab_smooth_residual(D, R, l, 0, 2, keep ? nullptr : gc, keep ? nullptr : dc, lo, hi);
+            k_restrict(sl.lv.g, sl.lv.f[MG3D_R], *gc, dc, s, lo, hi, !keep);
         }
         if (l - 1 >= ld)
             CHK(exchange_halo(D, MG3D_D, l - 1));

@@ -46,7 +46,7 @@ void k_residual(const Geom &g, const double *v, const double *d, double invHsq, 
 void k_sumsq(const Geom &g, const double *a, double *partials, double *sumsq_out, hipStream_t s);
 /* ic_lo/ic_hi, if_lo/if_hi: local plane range to produce; -1 = every local plane that is not a slab halo */
 void k_restrict(const Geom &gf, const double *r, const Geom &gc, double *dc, hipStream_t s, int ic_lo = -1,
-                int ic_hi = -1);
+                int ic_hi = -1, bool faces_only = false /* injection on the coarse faces only */);
 void k_prolong(const Geom &gc, const double *ec, const Geom &gf, double *ef, hipStream_t s, int if_lo = -1,
                int if_hi = -1);
 /* folds np per-block partial sums, in a fixed order, into *out */
@@ -57,7 +57,10 @@ void k_fold(const double *partials, int np, double *out, hipStream_t s);
  * of partials written (>= 0) or -1 when the (S, residual) shape has no instantiation. */
 int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
             int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo = 0,
-            int acc_hi = -1 /* local planes entering the norm; default all */);
+            int acc_hi = -1 /* local planes entering the norm; default all */,
+            const Geom *gc = nullptr, double *dc = nullptr /* non-NULL: also restrict the residual into the
+            interior of the coarse right-hand side dc (S = 0 or 2 with residual only) */,
+            int ic_lo = -1, int ic_hi = -1 /* local coarse planes to write; default all */);
 /* b and x are level-0 grids in the padded layout g0; work holds 2n doubles */
 void k_lu_solve(const LuBand &lu, const Geom &g0, const double *b_pad, double *x_pad, double *work, hipStream_t s);
 

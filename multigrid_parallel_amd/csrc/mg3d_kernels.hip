@@ -189,7 +189,7 @@ void k_sumsq(const Geom &g, const double *a, double *partials, double *sumsq_out
  * "Face" in i means a PHYSICAL boundary plane (global index 0 or Nc-1); the
  * fine plane of coarse local plane ic is 2*(gc.ig0+ic) - gf.ig0. */
 __global__ void __launch_bounds__(256) restrict_kernel(Geom gf, const double *__restrict__ r, Geom gc,
-                                                       double *__restrict__ dc, int ic_lo, int ic_hi)
+                                                       double *__restrict__ dc, int ic_lo, int ic_hi, int faces_only)
 {
     const int kc = blockIdx.x * 64 + threadIdx.x;
     const int jc = blockIdx.y * 4 + threadIdx.y;
@@ -203,6 +203,8 @@ __global__ void __launch_bounds__(256) restrict_kernel(Geom gf, const double *__
     double val;
     if (face) {
         val = r[pf];
+    } else if (faces_only) {
+        return;
     } else {
         val = 0.;
 #pragma unroll
@@ -218,7 +220,8 @@ __global__ void __launch_bounds__(256) restrict_kernel(Geom gf, const double *__
     dc[gidx(gc, ic, jc, kc)] = val;
 }
 
-void k_restrict(const Geom &gf, const double *r, const Geom &gc, double *dc, hipStream_t s, int ic_lo, int ic_hi)
+void k_restrict(const Geom &gf, const double *r, const Geom &gc, double *dc, hipStream_t s, int ic_lo, int ic_hi,
+                bool faces_only)
 {
     /* local coarse planes written: physical boundary planes and owned planes; a
      * halo plane (local 0 / ni-1 that is not a physical boundary) is the neighbour's */
@@ -227,7 +230,7 @@ void k_restrict(const Geom &gf, const double *r, const Geom &gc, double *dc, hip
     if (hi <= lo)
         return;
     dim3 grid((gc.nk + 63) / 64, (gc.nj + 3) / 4, hi - lo);
-    hipLaunchKernelGGL(restrict_kernel, grid, dim3(64, 4, 1), 0, s, gf, r, gc, dc, lo, hi);
+    hipLaunchKernelGGL(restrict_kernel, grid, dim3(64, 4, 1), 0, s, gf, r, gc, dc, lo, hi, faces_only ? 1 : 0);
 }
 
 /* -------------------------------------------------------------- prolongation

@@ -57,16 +57,24 @@ struct SweepArgs {
     int ntj, ntk;   /* tiles in j, k */
     int CI, nci;    /* planes per i-chunk, number of chunks */
     int acc_lo, acc_hi; /* local planes whose diff^2 enter the norm (owned planes of a slab) */
+    /* fused restriction (RES == 2): coarse geometry, coarse right-hand side, local coarse planes to write */
+    Geom gc;
+    double *dc;
+    int ic_lo, ic_hi;
     int xcd_remap;  /* 1: renumber blocks so that consecutive tiles share an XCD (and its L2) */
 };
 
-template <int S, bool RES> struct SweepShape {
+/* RES: 0 = smoothing only, 1 = + residual (r store and/or norm), 2 = + residual AND full-weighting
+ * restriction of it into the coarse right-hand side (mg_3d.h:961-995) -- r never travels to HBM.
+ * The 27-point restriction stencil reaches one fine point beyond the coarse point's centre, so its halo
+ * and warm-up are one deeper. */
+template <int S, int RES> struct SweepShape {
     /* With S > 0 the residual of the colour updated last falls out of stage S itself (same neighbour
      * sum), the other colour needs one more gather: ST = S + 1.  A pure residual (S == 0) needs both. */
     static constexpr int ST = S + (RES ? (S > 0 ? 1 : 2) : 0); /* pipeline stages */
-    static constexpr int HJ = S + (RES ? 1 : 0); /* halo rows */
+    static constexpr int HJ = S + (RES ? 1 : 0) + (RES == 2 ? 1 : 0); /* halo rows */
     static constexpr int HK = (HJ + 1) & ~1;     /* halo columns, even so pairs stay aligned */
-    static constexpr int HI = S + (RES ? 1 : 0); /* warm-up planes */
+    static constexpr int HI = S + (RES ? 1 : 0) + (RES == 2 ? 1 : 0); /* warm-up planes */
 };
 
 /* One-lane shifts across the whole wave as DPP moves (v_mov_b32_dpp wave_shr:1 / wave_shl:1, two per
@@ -96,7 +104,7 @@ __device__ __forceinline__ double lane_from_right(double x) /* lane l receives l
 #endif
 }
 
-template <int S, bool RES, int RJ, int NW, int PF>
+template <int S, int RES, int RJ, int NW, int PF>
 __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 {
     using Sh = SweepShape<S, RES>;
@@ -109,6 +117,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     /* edge rows exchanged between waves: [parity][wave][top/bottom][stage][lane] */
     __shared__ double ex[2][NW][2][STX][WAVE];
     __shared__ double red[NW];
+    __shared__ double2 rex[RES == 2 ? 2 : 1][RES == 2 ? NW : 1][RES == 2 ? WAVE : 1]; /* last row's r pair per wave */
 
     const Geom &g = a.g;
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
@@ -132,7 +141,8 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
      * local step p in row rr is (p + rr) & 1 */
     int i_s = i_out0 - HI;
     i_s -= (g.ig0 + i_s + jt0 + 1 + a.c1) & 1;
-    const int nsteps = (i_out1 - 1 + ST) - i_s + 1;
+    /* the fused restriction finishes a coarse plane one fine plane after its centre, one step late */
+    const int nsteps = (i_out1 - 1 + ST) - i_s + 1 + (RES == 2 ? 2 : 0);
 
     /* per-row / per-column masks */
     bool row_in[RJ], row_upd[RJ], row_own[RJ];
@@ -166,6 +176,14 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         cur_v[rr] = make_double2(0., 0.);
     }
     double acc = 0.;
+    double2 rcur[RJ], rlag[RJ]; /* RES == 2: r pairs of the plane finished this step / the step before */
+    double racc[RJ / 2];        /* running 27-point sums, one per coarse row centred in this thread's rows */
+#pragma unroll
+    for (int rr = 0; rr < RJ; rr++)
+        rcur[rr] = rlag[rr] = make_double2(0., 0.);
+#pragma unroll
+    for (int c = 0; c < RJ / 2; c++)
+        racc[c] = 0.;
 
     auto load_plane = [&](int i, double2(&vv)[RJ], double2(&dd)[RJ]) {
         const bool pl = i >= 0 && i < g.ni;
@@ -280,13 +298,14 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                     *reinterpret_cast<double2 *>(a.vout + g.plane * q + row_off[rr]) = o;
                 }
             }
-            if constexpr (RES) {
+            if constexpr (RES != 0) {
                 const int q = i - ST;
+                /* column X: the residual-only stage now; column X^1: the previous step's diff */
+                double2 o;
+                o.x = X ? rkeep[rr] : diffs[1];
+                o.y = X ? diffs[1] : rkeep[rr];
+                rcur[rr] = o;
                 if (a.r && q >= i_out0 && q < i_out1 && row_own[rr] && pair_own && row_upd[rr] && pl_upd[ST]) {
-                    /* column X: the residual-only stage now; column X^1: the previous step's diff */
-                    double2 o;
-                    o.x = X ? rkeep[rr] : diffs[1];
-                    o.y = X ? diffs[1] : rkeep[rr];
                     double *dst = a.r + g.plane * q + row_off[rr];
                     if (col_upd[0] && col_upd[1])
                         *reinterpret_cast<double2 *>(dst) = o;
@@ -303,6 +322,48 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 #pragma unroll
             for (int s = 0; s < ST; s++)
                 last[rr][s][X] = nw[s];
+        }
+        if constexpr (RES == 2) {
+            /* Full weighting of plane qq = i-ST-1 (its r pairs are in rlag; the row above this wave's first
+             * row was published by the wave above at the end of the previous step).  Coarse row centres sit
+             * on this thread's even rows rr = 0, 2, ..; coarse column = this lane's even column kA.  The
+             * reference adds the 27 products r*w in the order ti, tj, tk (mg_3d.h:980-988): planes arrive
+             * in ti order, and inside a plane the nine terms below are tj-major, tk-minor. */
+            const int qq = i - ST - 1, qg = g.ig0 + qq;
+            const bool odd = (qg & 1) != 0;
+            const double wi = odd ? 0.25 : 0.5;
+            const double2 top = (w > 0) ? rex[par ^ 1][w - 1][lane] : make_double2(0., 0.);
+#pragma unroll
+            for (int c = 0; c < RJ / 2; c++) {
+                const double2 r0 = c == 0 ? top : rlag[2 * c - 1], r1 = rlag[2 * c], r2 = rlag[2 * c + 1];
+                const double l0 = lane_from_left(r0.y), l1 = lane_from_left(r1.y), l2 = lane_from_left(r2.y);
+                const double p[9] = {l0 * (wi * 0.25 * 0.25), r0.x * (wi * 0.25 * 0.5), r0.y * (wi * 0.25 * 0.25),
+                                     l1 * (wi * 0.5 * 0.25),  r1.x * (wi * 0.5 * 0.5),  r1.y * (wi * 0.5 * 0.25),
+                                     l2 * (wi * 0.25 * 0.25), r2.x * (wi * 0.25 * 0.5), r2.y * (wi * 0.25 * 0.25)};
+                double run = racc[c];
+#pragma unroll
+                for (int t = 0; t < 9; t++)
+                    run = run + p[t];
+                if (odd) {
+                    /* qq is the ti = 2 plane of coarse plane (qg-1)/2 and the ti = 0 plane of (qg+1)/2 */
+                    const int icg = (qg - 1) >> 1, icl = icg - a.gc.ig0, cen = qq - 1;
+                    const int jc = (jrow0 + 2 * c) >> 1, kc = kA >> 1;
+                    if (cen >= i_out0 && cen < i_out1 && icg >= 1 && icg <= a.gc.N - 2 && icl >= a.ic_lo && icl < a.ic_hi &&
+                        row_own[2 * c] && jc >= 1 && jc <= a.gc.nj - 2 && pair_own && kc >= 1 && kc <= a.gc.nk - 2)
+                        a.dc[a.gc.plane * icl + (long long)a.gc.pitch * jc + kc] = run;
+                    double fresh = 0.;
+#pragma unroll
+                    for (int t = 0; t < 9; t++)
+                        fresh = fresh + p[t];
+                    racc[c] = fresh;
+                } else {
+                    racc[c] = run;
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < RJ; rr++)
+                rlag[rr] = rcur[rr];
+            rex[par][w][lane] = rcur[RJ - 1];
         }
         /* age the d window */
 #pragma unroll
@@ -346,7 +407,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 }
 
 /* -------------------------------------------------------------------- launch */
-template <int S, bool RES, int RJ, int NW, int PF>
+template <int S, int RES, int RJ, int NW, int PF>
 static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
 {
     using Sh = SweepShape<S, RES>;
@@ -401,40 +462,61 @@ static SweepCfg env_cfg(SweepCfg dflt)
     if (c.rj == RJ_ && c.nw == NW_ && c.pf == PF_)                                \
         return launch_sweep<S_, RES_, RJ_, NW_, PF_>(a, max_partials, s);
 
-template <int S, bool RES> static int dispatch(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s);
+template <int S, int RES> static int dispatch(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s);
 
-template <> int dispatch<4, true>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<4, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
-    TRY(4, true, 6, 4, 1) TRY(4, true, 6, 4, 2) TRY(4, true, 4, 4, 2) TRY(4, true, 4, 8, 1) TRY(4, true, 2, 8, 2)
+    TRY(4, 1, 6, 4, 1) TRY(4, 1, 6, 4, 2) TRY(4, 1, 4, 4, 2) TRY(4, 1, 4, 8, 1) TRY(4, 1, 2, 8, 2)
     return -1;
 }
-template <> int dispatch<4, false>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<4, 0>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
-    TRY(4, false, 8, 4, 1) TRY(4, false, 6, 4, 2) TRY(4, false, 6, 4, 3) TRY(4, false, 4, 8, 1) TRY(4, false, 4, 8, 2)
+    TRY(4, 0, 8, 4, 1) TRY(4, 0, 6, 4, 2) TRY(4, 0, 6, 4, 3) TRY(4, 0, 4, 8, 1) TRY(4, 0, 4, 8, 2)
     return -1;
 }
-template <> int dispatch<2, true>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<2, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
-    TRY(2, true, 4, 8, 1) TRY(2, true, 8, 4, 2) TRY(2, true, 6, 4, 2)
+    TRY(2, 1, 4, 8, 1) TRY(2, 1, 8, 4, 2) TRY(2, 1, 6, 4, 2)
     return -1;
 }
-template <> int dispatch<2, false>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<2, 0>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
-    TRY(2, false, 6, 8, 1) TRY(2, false, 8, 4, 2) TRY(2, false, 4, 8, 1) TRY(2, false, 4, 8, 2) TRY(2, false, 4, 8, 3)
+    TRY(2, 0, 6, 8, 1) TRY(2, 0, 8, 4, 2) TRY(2, 0, 4, 8, 1) TRY(2, 0, 4, 8, 2) TRY(2, 0, 4, 8, 3)
     return -1;
 }
-template <> int dispatch<0, true>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<0, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
-    TRY(0, true, 4, 8, 1) TRY(0, true, 8, 4, 2) TRY(0, true, 4, 8, 2) TRY(0, true, 4, 8, 3) TRY(0, true, 2, 8, 4)
+    TRY(0, 1, 4, 8, 1) TRY(0, 1, 8, 4, 2) TRY(0, 1, 4, 8, 2) TRY(0, 1, 4, 8, 3) TRY(0, 1, 2, 8, 4)
     return -1;
 }
 
 /* S colour passes starting with colour c1, optional residual.  Returns the number of
  * partial sums written (0 when no norm was requested), -1 if the shape is unsupported. */
+template <> int dispatch<0, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+{
+    TRY(0, 2, 4, 8, 1) TRY(0, 2, 4, 8, 2)
+    return -1;
+}
+template <> int dispatch<2, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+{
+    TRY(2, 2, 4, 8, 1) TRY(2, 2, 4, 4, 1)
+    return -1;
+}
+
 int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
-            int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo, int acc_hi)
+            int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo, int acc_hi,
+            const Geom *gc, double *dc, int ic_lo, int ic_hi)
 {
     SweepArgs a;
+    a.dc = dc;
+    if (dc) {
+        a.gc = *gc;
+        a.ic_lo = ic_lo >= 0 ? ic_lo : 0;
+        a.ic_hi = ic_hi >= 0 ? ic_hi : gc->ni;
+    } else {
+        a.gc = g;
+        a.ic_lo = a.ic_hi = 0;
+    }
     a.acc_lo = acc_lo;
     a.acc_hi = acc_hi < 0 ? g.ni : acc_hi;
     a.g = g;
@@ -447,15 +529,21 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
     a.sixth = 1. / 6;        /* mg_3d.h:646 */
     a.invHsq = 1. / (h * h); /* mg_3d.h:797 */
     a.c1 = c1;
+    if (dc && S == 0 && residual)
+        return dispatch<0, 2>(a, env_cfg({4, 8, 1}), max_partials, s);
+    if (dc && S == 2 && residual)
+        return dispatch<2, 2>(a, env_cfg({4, 8, 1}), max_partials, s);
+    if (dc)
+        return -1;
     if (S == 4 && residual)
-        return dispatch<4, true>(a, env_cfg({6, 4, 2}), max_partials, s);
+        return dispatch<4, 1>(a, env_cfg({6, 4, 2}), max_partials, s);
     if (S == 4 && !residual)
-        return dispatch<4, false>(a, env_cfg({4, 8, 1}), max_partials, s);
+        return dispatch<4, 0>(a, env_cfg({4, 8, 1}), max_partials, s);
     if (S == 2 && residual)
-        return dispatch<2, true>(a, env_cfg({4, 8, 1}), max_partials, s);
+        return dispatch<2, 1>(a, env_cfg({4, 8, 1}), max_partials, s);
     if (S == 2 && !residual)
-        return dispatch<2, false>(a, env_cfg({4, 8, 1}), max_partials, s);
+        return dispatch<2, 0>(a, env_cfg({4, 8, 1}), max_partials, s);
     if (S == 0 && residual)
-        return dispatch<0, true>(a, env_cfg({4, 8, 1}), max_partials, s);
+        return dispatch<0, 1>(a, env_cfg({4, 8, 1}), max_partials, s);
     return -1;
 }

@@ -35,6 +35,8 @@ def test_slab_vcycles_match_single_domain(c, L, nu, P):
 def test_slab_intermediate_levels_match_single_domain():
     c, L, nu, P = 9, 5, 2, 4
     with M.Solver(c, L, nu) as s, M.DistSolver(c, L, nu, nranks=P) as d:
+        s.set_keep_residual(True)
+        d.set_keep_residual(True)
         s.setup_test_problem()
         d.setup_test_problem()
         s.vcycles(2)

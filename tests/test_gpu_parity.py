@@ -197,6 +197,7 @@ def test_intermediate_levels_match_oracle_after_one_cycle():
     O.lib().orc_set_threads(1)
     wn = O.lib().orc_vcycle(H.ptrs(H.u), H.ptrs(H.d), H.ptrs(H.r), h, L - 1, L, nu, N, O.P(LU))
     with M.Solver(c, L, nu) as s:
+        s.set_keep_residual(True)  # r is a reference-visible array; by default it is restricted on the fly
         s.setup_test_problem()
         gn = s.lin_solve()
         assert gn == pytest.approx(wn, rel=NORM_RTOL)
@@ -262,9 +263,27 @@ def test_unfused_kernel_set_gives_identical_results(monkeypatch):
     for flag in ("0", "1"):
         monkeypatch.setenv("MG3D_NO_FUSE", flag)
         with M.Solver(5, 5, 3) as s:  # nu = 3: the fused path chains a 4-pass and a 2-pass launch
+            s.set_keep_residual(True)
             s.setup_test_problem()
             norms = s.vcycles(5)
             outs.append((norms, s.download(MG3D_U, 4), s.download(MG3D_R, 3), s.download(MG3D_D, 2)))
     assert np.array_equal(outs[0][0], outs[1][0]) or np.allclose(outs[0][0], outs[1][0], rtol=1e-12, atol=0)
     for a, b in zip(outs[0][1:], outs[1][1:]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("c,L,nu", [(5, 5, 2), (9, 4, 1), (5, 4, 3), (3, 6, 2)])
+def test_on_the_fly_restriction_equals_materialised_residual(c, L, nu):
+    """Default mode (residual restricted on the fly, r never stored) against keep_residual mode: u, d on every
+    level and the norms must be identical bit for bit."""
+    res = []
+    for keep in (False, True):
+        with M.Solver(c, L, nu) as s:
+            s.set_keep_residual(keep)
+            s.setup_test_problem()
+            norms = s.vcycles(4)
+            res.append((norms, [s.download(MG3D_U, l) for l in range(L)], [s.download(MG3D_D, l) for l in range(L)]))
+    assert np.array_equal(res[0][0], res[1][0])
+    for l in range(L):
+        assert np.array_equal(res[0][1][l], res[1][1][l]), f"u level {l}"
+        assert np.array_equal(res[0][2][l], res[1][2][l]), f"d level {l}"
