@@ -92,6 +92,8 @@ int mg3d_residual(mg3d_ctx *ctx, int level, int store, double *norm);
 /* smoother followed by the residual of its result, as vcycle does back to back (mg_3d.h:1282+1294,
  * 1341+1354), in ONE pass over the level (fused sweep kernel) */
 int mg3d_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters, int store, double *norm);
+/* smoother, residual and restriction of it into d[level-1] (mg_3d.h:1282+1294+1310) without storing r */
+int mg3d_smooth_restrict(mg3d_ctx *ctx, int level, int iters);
 int mg3d_restrict(mg3d_ctx *ctx, int level);
 int mg3d_prolong(mg3d_ctx *ctx, int level);
 int mg3d_coarse_solve(mg3d_ctx *ctx);

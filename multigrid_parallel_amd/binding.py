@@ -49,6 +49,7 @@ SIGNATURES = {
     "mg3d_smooth": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mg3d_residual": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
     "mg3d_smooth_residual": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp]),
+    "mg3d_smooth_restrict": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mg3d_restrict": (C.c_int, [C.c_void_p, C.c_int]),
     "mg3d_prolong": (C.c_int, [C.c_void_p, C.c_int]),
     "mg3d_coarse_solve": (C.c_int, [C.c_void_p]),
@@ -238,6 +239,9 @@ class Solver:
         check(self.L.mg3d_smooth_residual(self._h, level, int(post), iters, int(store),
                                           C.byref(nrm) if want_norm else None))
         return nrm.value
+
+    def smooth_restrict(self, level, iters):
+        check(self.L.mg3d_smooth_restrict(self._h, level, iters))
 
     def restrict(self, level):
         check(self.L.mg3d_restrict(self._h, level))

@@ -575,6 +575,17 @@ extern "C" int mg3d_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
     return read_norm(ctx, 0, norm);
 }
 
+extern "C" int mg3d_smooth_restrict(mg3d_ctx *ctx, int level, int iters)
+{
+    CHK(check_field_level(ctx, 0, level, "mg3d_smooth_restrict"));
+    if (level < 1 || iters < 0)
+        return fail(MG3D_ERR_ARG, "mg3d_smooth_restrict: bad level/iteration count");
+    Level &lev = ctx->lv[level], &lc = ctx->lv[level - 1];
+    enqueue_smooth_residual(ctx, level, 0, iters, 2, ctx->sumsq_slots - 1, ctx->fused ? &lc : nullptr);
+    k_restrict(lev.g, lev.f[MG3D_R], lc.g, lc.f[MG3D_D], ctx->stream, -1, -1, ctx->fused);
+    return launch_ok("mg3d_smooth_restrict");
+}
+
 extern "C" int mg3d_restrict(mg3d_ctx *ctx, int level)
 {
     CHK(check_field_level(ctx, 0, level, "mg3d_restrict"));

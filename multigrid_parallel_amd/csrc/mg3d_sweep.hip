@@ -419,8 +419,8 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
      * 256 CUs busy and short chunks mean fewer dependent steps.  Measured optimum on MI355X: about
      * 500-1000 blocks (513^3: CI 64-128, 257^3: 16, 129^3: 8, <= 65^3: 2-4). */
     auto blocks = [&](int ci) { return (long long)a.ntj * a.ntk * ((g.ni + ci - 1) / ci); };
-    int CI = 8;
-    const long long most = Sh::ST <= 2 ? 1600 : 800; /* a short pipeline tolerates shorter chunks */
+    int CI = RES == 2 ? 16 : 8; /* the fused restriction pays two more warm-up planes and two drain steps */
+    const long long most = RES == 2 ? 1000 : Sh::ST <= 2 ? 1600 : 800; /* a short pipeline tolerates shorter chunks */
     while (CI < 128 && blocks(CI) > most)
         CI *= 2;
     while (CI > 2 && blocks(CI) < 100)
@@ -499,7 +499,7 @@ template <> int dispatch<0, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
 }
 template <> int dispatch<2, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
-    TRY(2, 2, 4, 8, 1) TRY(2, 2, 4, 4, 1)
+    TRY(2, 2, 4, 8, 1)
     return -1;
 }
 
@@ -530,7 +530,7 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
     a.invHsq = 1. / (h * h); /* mg_3d.h:797 */
     a.c1 = c1;
     if (dc && S == 0 && residual)
-        return dispatch<0, 2>(a, env_cfg({4, 8, 1}), max_partials, s);
+        return dispatch<0, 2>(a, env_cfg({4, 8, 2}), max_partials, s);
     if (dc && S == 2 && residual)
         return dispatch<2, 2>(a, env_cfg({4, 8, 1}), max_partials, s);
     if (dc)

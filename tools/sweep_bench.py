@@ -39,6 +39,8 @@ cases = {
     "S2RES": (lambda: s.smooth_residual(lev, 0, 1, True, False), (3 + 3) * n * 8, ["4,8,1", "8,4,2", "6,4,2"]),
     "S2": (lambda: s.smooth(lev, 0, 1), 3 * n * 8, ["6,8,1", "8,4,2", "4,8,1"]),
     "S0RES": (lambda: s.residual(lev, True, False), 3 * n * 8, ["4,8,1", "8,4,2", "4,8,2", "4,8,3", "2,8,4"]),
+    "S0RST": (lambda: s.smooth_restrict(lev, 0), 4.125 * n * 8, ["4,8,1", "4,8,2"]),
+    "S2RST": (lambda: s.smooth_restrict(lev, 1), 7.125 * n * 8, ["4,8,1"]),
     "S0NORM": (lambda: s.residual(lev, False, False), 2 * n * 8, ["4,8,1", "8,4,2", "4,8,2", "4,8,3", "2,8,4"]),
 }
 only = os.environ.get("ONLY")
