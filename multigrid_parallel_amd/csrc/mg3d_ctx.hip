@@ -485,8 +485,10 @@ static int read_norm(mg3d_ctx *ctx, int slot, double *norm)
  * alternate buffer; the residual rides on the last launch.  want_res: 0 none, 1 norm only,
  * 2 store r (+ norm).  The squared norm goes to sumsq[slot]. */
 static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters, int want_res, int slot,
-                                    Level *coarse = nullptr)
+                                    Level *coarse = nullptr, const Level *pro = nullptr)
 {
+    /* pro != NULL: the smoother's input is u + P(pro->u) (prolongateAndCorrectError, mg_3d.h:1331, folded
+     * into the first launch's loads); the caller must have checked pro_fusable() */
     /* coarse != NULL (with want_res != 0): the residual is restricted on the fly into the interior of
      * coarse->d and never stored; the caller adds the face injection (k_restrict, faces_only) */
     Level &l = ctx->lv[level];
@@ -503,6 +505,7 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
              * against 0.85 + 0.76 ms split on a 513^3 level) */
             const bool res = last && want_res != 0 && S != 4;
             const bool rst = res && coarse != nullptr;
+            const bool with_pro = pro != nullptr && passes == 2 * iters; /* first launch only */
             int np;
             {
                 StageScope kt(ctx, level, S == 4 ? MG3D_K_SWEEP4 : S == 2 ? (res ? MG3D_K_SWEEP2_RES : MG3D_K_SWEEP2)
@@ -510,7 +513,8 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
                 np = k_sweep(l.g, l.f[MG3D_U], l.f[MG3D_D], l.alt,
                              (res && want_res == 2 && !rst) ? l.f[MG3D_R] : nullptr, res ? ctx->partials : nullptr,
                              MG3D_MAX_PARTIALS, l.h, S, c1, res, s, 0, -1, rst ? &coarse->g : nullptr,
-                             rst ? coarse->f[MG3D_D] : nullptr);
+                             rst ? coarse->f[MG3D_D] : nullptr, -1, -1, with_pro ? &pro->g : nullptr,
+                             with_pro ? pro->f[MG3D_U] : nullptr);
             }
             if (S > 0) {
                 double *t = l.f[MG3D_U];
@@ -536,6 +540,20 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
         k_residual(l.g, l.f[MG3D_U], l.f[MG3D_D], invHsq, want_res == 2 ? l.f[MG3D_R] : nullptr, ctx->partials,
                    ctx->sumsq + slot, s);
     }
+}
+
+/* can the prolongation ride on the first smoothing launch?  (needs a smoothing-only first launch) */
+static bool pro_fusable(const mg3d_ctx *ctx, int iters, int want_res)
+{
+    /* Opt-in (MG3D_PRO_FUSE=1): bit-identical, but measured SLOWER on MI355X at 513^3 -- the 4-pass sweep
+     * already uses 249 VGPRs, the prologue spills 44 dwords and the launch takes 1.48 ms against
+     * 0.85 ms (sweep) + 0.56 ms (separate prolongation kernel). */
+    static const bool on = getenv("MG3D_PRO_FUSE") && getenv("MG3D_PRO_FUSE")[0] == '1';
+    if (!on || !ctx->fused || iters < 1)
+        return false;
+    const int first = 2 * iters >= 4 ? 4 : 2;
+    const bool first_has_res = want_res != 0 && first == 2 && 2 * iters == 2;
+    return !first_has_res;
 }
 
 static void enqueue_smooth(mg3d_ctx *ctx, int level, int post, int iters)
@@ -670,17 +688,22 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
     }
     for (int l = 1; l <= q; l++) {
         Level &lev = ctx->lv[l];
+        const int want_norm = l == q ? 1 : 0;
+        const bool pro = pro_fusable(ctx, ctx->iters, want_norm);
         {
-            StageScope t(ctx, l, MG3D_ST_PROLONG);
-            StageScope kt(ctx, l, MG3D_K_PROLONG, true);
-            k_prolong(ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_U], lev.g, lev.f[MG3D_U], s); /* :1331 */
+            StageScope t(ctx, l, MG3D_ST_PROLONG); /* :1331; ~0 s when folded into the smoother's loads */
+            if (!pro) {
+                StageScope kt(ctx, l, MG3D_K_PROLONG, true);
+                k_prolong(ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_U], lev.g, lev.f[MG3D_U], s);
+            }
         }
-        if (ctx->fused) { /* post-smoother and residual norm in one pass (:1341 + :1354) */
+        if (ctx->fused) { /* (prolongation,) post-smoother and residual norm (:1331 + :1341 + :1354) */
             {
                 StageScope t(ctx, l, MG3D_ST_SMOOTH2);
                 /* the norm of a level below the top one is computed and dropped by the reference (:1320
                  * ignores the recursive call's value): skip it, nothing observable changes */
-                enqueue_smooth_residual(ctx, l, 1, ctx->iters, l == q ? 1 : 0, slot);
+                enqueue_smooth_residual(ctx, l, 1, ctx->iters, want_norm, slot, nullptr,
+                                        pro ? &ctx->lv[l - 1] : nullptr);
             }
             StageScope t(ctx, l, MG3D_ST_RESIDUAL2); /* fused into the launch above: counted, ~0 s */
         } else {

@@ -60,7 +60,9 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
             int acc_hi = -1 /* local planes entering the norm; default all */,
             const Geom *gc = nullptr, double *dc = nullptr /* non-NULL: also restrict the residual into the
             interior of the coarse right-hand side dc (S = 0 or 2 with residual only) */,
-            int ic_lo = -1, int ic_hi = -1 /* local coarse planes to write; default all */);
+            int ic_lo = -1, int ic_hi = -1 /* local coarse planes to write; default all */,
+            const Geom *gce = nullptr, const double *ec = nullptr /* non-NULL: the input is vin + P(ec), the
+            trilinear prolongation of the coarse field ec (smoothing-only launches, S = 2 or 4) */);
 /* b and x are level-0 grids in the padded layout g0; work holds 2n doubles */
 void k_lu_solve(const LuBand &lu, const Geom &g0, const double *b_pad, double *x_pad, double *work, hipStream_t s);
 

@@ -57,6 +57,9 @@ struct SweepArgs {
     int ntj, ntk;   /* tiles in j, k */
     int CI, nci;    /* planes per i-chunk, number of chunks */
     int acc_lo, acc_hi; /* local planes whose diff^2 enter the norm (owned planes of a slab) */
+    /* fused prolongation (PRO): the level's input is vin + P(ec) (mg_3d.h:1000-1145); gce = geometry of ec */
+    const double *ec;
+    Geom gce;
     /* fused restriction (RES == 2): coarse geometry, coarse right-hand side, local coarse planes to write */
     Geom gc;
     double *dc;
@@ -104,7 +107,7 @@ __device__ __forceinline__ double lane_from_right(double x) /* lane l receives l
 #endif
 }
 
-template <int S, int RES, int RJ, int NW, int PF>
+template <int S, int RES, int RJ, int NW, int PF, bool PRO>
 __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 {
     using Sh = SweepShape<S, RES>;
@@ -118,6 +121,9 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     __shared__ double ex[2][NW][2][STX][WAVE];
     __shared__ double red[NW];
     __shared__ double2 rex[RES == 2 ? 2 : 1][RES == 2 ? NW : 1][RES == 2 ? WAVE : 1]; /* last row's r pair per wave */
+    /* PRO: three consecutive coarse planes of the tile's coarse footprint, [plane % 3][row][col] */
+    constexpr int CRW = PRO ? (NW * RJ) / 2 + 2 : 1, CCW = PRO ? WAVE + 2 : 1;
+    __shared__ double cpl[PRO ? 3 : 1][CRW][CCW];
 
     const Geom &g = a.g;
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
@@ -200,6 +206,47 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         }
     };
 
+    /* ---- PRO: coarse planes staged in LDS.  Plane c (local coarse index) lives in slot c mod 3. */
+    const int jcb = jt0 >> 1, kcb = kt0 >> 1; /* coarse origin of the tile (jt0, kt0 are even) */
+    auto coarse_of = [&](int i) { /* lower coarse parent plane (local) of fine local plane i */
+        const int ig = g.ig0 + i, oi = ig & 1;
+        return (ig - oi) / 2 - a.gce.ig0;
+    };
+    auto slot_of = [](int c) { return ((c % 3) + 3) % 3; };
+    constexpr int CPT = PRO ? (CRW * CCW + NW * WAVE - 1) / (NW * WAVE) : 1; /* staged values per thread */
+    auto coarse_fetch = [&](int c, double(&buf)[CPT]) {
+#pragma unroll
+        for (int t = 0; t < CPT; t++) {
+            const int idx = threadIdx.x + t * NW * WAVE;
+            const int row = idx / CCW, col = idx - row * CCW;
+            const int jc = jcb + row, kc = kcb + col;
+            const bool ok = idx < CRW * CCW && c >= 0 && c < a.gce.ni && jc >= 0 && jc < a.gce.nj && kc >= 0 &&
+                            kc < a.gce.nk;
+            buf[t] = ok ? a.ec[a.gce.plane * c + (long long)a.gce.pitch * jc + kc] : 0.;
+        }
+    };
+    auto coarse_put = [&](int c, const double(&buf)[CPT]) {
+        const int sl = slot_of(c);
+#pragma unroll
+        for (int t = 0; t < CPT; t++) {
+            const int idx = threadIdx.x + t * NW * WAVE;
+            if (idx < CRW * CCW)
+                (&cpl[sl][0][0])[idx] = buf[t];
+        }
+    };
+    int have_hi = 0; /* highest coarse plane staged so far */
+    if constexpr (PRO) {
+        double buf[CPT];
+        const int c0 = coarse_of(i_s);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            coarse_fetch(c0 + c, buf);
+            coarse_put(c0 + c, buf);
+        }
+        have_hi = c0 + 1;
+        __syncthreads();
+    }
+
     /* prime the prefetch queue with planes i_s .. i_s+PF-1 */
 #pragma unroll
     for (int f = 0; f < PF; f++)
@@ -222,6 +269,51 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
             }
         }
         load_plane(i + PF, nxt_v[PF - 1], nxt_d[PF - 1]);
+        double cbuf[CPT];
+        bool stage_new = false;
+        if constexpr (PRO) {
+            /* the next step needs coarse planes up to coarse_of(i+1)+1: fetch one now, publish before the barrier */
+            stage_new = coarse_of(i + 1) + 1 > have_hi;
+            if (stage_new)
+                coarse_fetch(have_hi + 1, cbuf);
+            /* v_in = u + P(ec): parents summed in the reference's order per parity class (see prolong_kernel) */
+            const int ig = g.ig0 + i, oi = ig & 1;
+            const int s0 = slot_of(coarse_of(i)), s1 = slot_of(coarse_of(i) + 1);
+#pragma unroll
+            for (int rr = 0; rr < RJ; rr++) {
+                const int oj = rr & 1; /* jrow0 is even */
+                const int lr = (w * RJ + rr) >> 1;
+                const double e000 = cpl[s0][lr][lane], e001 = cpl[s0][lr][lane + 1];
+                double t0, t1;
+                if (!oi && !oj) {
+                    t0 = e000;
+                    t1 = (e000 + e001) * 0.5;
+                } else if (!oi) {
+                    const double e010 = cpl[s0][lr + 1][lane], e011 = cpl[s0][lr + 1][lane + 1];
+                    t0 = (e000 + e010) * 0.5;
+                    t1 = (((e000 + e010) + e001) + e011) * 0.25;
+                } else if (!oj) {
+                    const double e100 = cpl[s1][lr][lane], e101 = cpl[s1][lr][lane + 1];
+                    t0 = (e000 + e100) * 0.5;
+                    t1 = (((e000 + e100) + e001) + e101) * 0.25;
+                } else {
+                    const double e010 = cpl[s0][lr + 1][lane], e011 = cpl[s0][lr + 1][lane + 1];
+                    const double e100 = cpl[s1][lr][lane], e101 = cpl[s1][lr][lane + 1];
+                    const double e110 = cpl[s1][lr + 1][lane], e111 = cpl[s1][lr + 1][lane + 1];
+                    t0 = (((e000 + e010) + e100) + e110) * 0.25;
+                    double t = e000 + e001;
+                    t = t + e010;
+                    t = t + e011;
+                    t = t + e100;
+                    t = t + e101;
+                    t = t + e110;
+                    t = t + e111;
+                    t1 = t * 0.125;
+                }
+                cur_v[rr].x += t0;
+                cur_v[rr].y += t1;
+            }
+        }
 
         /* rows of the neighbouring waves, written at the end of the previous step */
         double e_top[STX], e_bot[STX];
@@ -379,6 +471,12 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
             ex[par][w][0][s][lane] = last[0][s][(PAR + 0) & 1];
             ex[par][w][1][s][lane] = last[RJ - 1][s][(PAR + RJ - 1) & 1];
         }
+        if constexpr (PRO) {
+            if (stage_new) {
+                coarse_put(have_hi + 1, cbuf);
+                have_hi++;
+            }
+        }
         __syncthreads();
     };
 
@@ -407,7 +505,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 }
 
 /* -------------------------------------------------------------------- launch */
-template <int S, int RES, int RJ, int NW, int PF>
+template <int S, int RES, int RJ, int NW, int PF, bool PRO = false>
 static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
 {
     using Sh = SweepShape<S, RES>;
@@ -438,7 +536,7 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
     const long long nb = (long long)a.ntj * a.ntk * a.nci;
     if (a.partials && nb > max_partials)
         return -1;
-    hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
+    hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
     return (int)nb;
 }
 
@@ -505,9 +603,11 @@ template <> int dispatch<2, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
 
 int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
             int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo, int acc_hi,
-            const Geom *gc, double *dc, int ic_lo, int ic_hi)
+            const Geom *gc, double *dc, int ic_lo, int ic_hi, const Geom *gce, const double *ec)
 {
     SweepArgs a;
+    a.ec = ec;
+    a.gce = gce ? *gce : g;
     a.dc = dc;
     if (dc) {
         a.gc = *gc;
@@ -529,6 +629,16 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
     a.sixth = 1. / 6;        /* mg_3d.h:646 */
     a.invHsq = 1. / (h * h); /* mg_3d.h:797 */
     a.c1 = c1;
+    if (ec) { /* prolongation fused into the input: 4- and 2-pass smoothing launches */
+        SweepCfg c = env_cfg({4, 8, 1});
+        if (dc || residual || (g.nj & 1) == 0)
+            return -1;
+        if (S == 4 && c.rj == 4 && c.nw == 8 && c.pf == 1)
+            return launch_sweep<4, 0, 4, 8, 1, true>(a, max_partials, s);
+        if (S == 2 && c.rj == 4 && c.nw == 8 && c.pf == 1)
+            return launch_sweep<2, 0, 4, 8, 1, true>(a, max_partials, s);
+        return -1;
+    }
     if (dc && S == 0 && residual)
         return dispatch<0, 2>(a, env_cfg({4, 8, 2}), max_partials, s);
     if (dc && S == 2 && residual)

@@ -287,3 +287,21 @@ def test_on_the_fly_restriction_equals_materialised_residual(c, L, nu):
     for l in range(L):
         assert np.array_equal(res[0][1][l], res[1][1][l]), f"u level {l}"
         assert np.array_equal(res[0][2][l], res[1][2][l]), f"d level {l}"
+
+
+@pytest.mark.parametrize("c,L,nu", [(5, 5, 2), (9, 4, 1), (5, 4, 3), (3, 6, 2), (9, 5, 2)])
+def test_prolongation_fused_into_smoother_equals_separate_launch(c, L, nu, monkeypatch):
+    """MG3D_PRO_FUSE=1 folds prolongateAndCorrectError into the post-smoother's loads (opt-in: measured slower);
+    by default it is its own kernel.  Same bits either way (and both equal the oracle, see the history tests)."""
+    import subprocess, sys, json
+    outs = []
+    for flag in ("0", "1"):
+        code = (f"import os,sys,hashlib,json; sys.path.insert(0,{os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r});"
+                f"import numpy as np, multigrid_parallel_amd as M;"
+                f"s=M.Solver({c},{L},{nu}); s.setup_test_problem(); n=s.vcycles(5);"
+                f"u=s.download(0,{L - 1}); print(json.dumps([list(n), hashlib.sha256(u.tobytes()).hexdigest()]))")
+        env = dict(os.environ, MG3D_PRO_FUSE=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
