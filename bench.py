@@ -217,13 +217,13 @@ def main():
     # (red + black pass) is credited 3*n*w bytes, so a launch fusing P colour passes is credited 1.5*P*n*w.
     if (fin, "sweep4") in kt:
         kname, passes = "sweep4", 4
-        kernel = "sweep_kernel<4,false,4,8,1> (4 fused colour passes = 2 RB sweeps, finest level)"
+        kernel = "sweep_kernel<S=4,RES=0,RJ=4,NW=8,PF=1> (4 fused colour passes = 2 RB sweeps, finest level)"
     elif (fin, "sweep2") in kt:
         kname, passes = "sweep2", 2
-        kernel = "sweep_kernel<2,false,4,8,1> (2 fused colour passes = 1 RB sweep, finest level)"
+        kernel = "sweep_kernel<S=2,RES=0,RJ=4,NW=8,PF=1> (2 fused colour passes = 1 RB sweep, finest level)"
     elif (fin, "sweep2+residual") in kt:
         kname, passes = "sweep2+residual", 2
-        kernel = "sweep_kernel<2,true,4,8,1> (1 RB sweep + residual, finest level)"
+        kernel = "sweep_kernel<S=2,RES=1,RJ=4,NW=8,PF=1> (1 RB sweep + residual, finest level)"
     else:
         kname, passes = "colour_pass", 1
         kernel = "smooth_color_kernel (one colour pass, finest level)"

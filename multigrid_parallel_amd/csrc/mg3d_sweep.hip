@@ -128,7 +128,16 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     const Geom &g = a.g;
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
     int b = blockIdx.x;
-    if (a.xcd_remap) {
+    if (a.xcd_remap == 2) {
+        /* banded: every chunk's tiles are dealt in 8 contiguous bands, band x to the blocks with b % 8 == x,
+         * so all XCDs sweep the same chunk at the same time and the j-halos of a band stay in one L2.
+         * The grid is padded to a multiple of 8 tiles per chunk; surplus blocks exit. */
+        const int per = (a.ntj * a.ntk + 7) >> 3, x = b & 7, idx = b >> 3;
+        const int cch = idx / per, t = x * per + idx % per;
+        if (t >= a.ntj * a.ntk)
+            return;
+        b = cch * a.ntj * a.ntk + t;
+    } else if (a.xcd_remap) {
         /* hardware deals blocks round-robin over the 8 XCDs (b % 8 names the XCD group, never which XCD);
          * give each group a contiguous run of tiles so halo re-reads hit that XCD's L2.  Speed only. */
         const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = b & 7, idx = b >> 3;
@@ -533,9 +542,15 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
     a.xcd_remap = 0;
     if (const char *e = getenv("MG3D_XCD"))
         a.xcd_remap = atoi(e);
-    const long long nb = (long long)a.ntj * a.ntk * a.nci;
+    if (a.xcd_remap == 2 && (long long)a.ntj * a.ntk < 16)
+        a.xcd_remap = 0;
+    long long nb = (long long)a.ntj * a.ntk * a.nci;
+    if (a.xcd_remap == 2)
+        nb = (long long)(((a.ntj * a.ntk + 7) >> 3) << 3) * a.nci;
     if (a.partials && nb > max_partials)
         return -1;
+    if (a.partials && a.xcd_remap == 2)
+        (void)hipMemsetAsync(a.partials, 0, sizeof(double) * nb, s); /* surplus blocks write nothing */
     hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
     return (int)nb;
 }

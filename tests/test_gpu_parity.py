@@ -305,3 +305,25 @@ def test_prolongation_fused_into_smoother_equals_separate_launch(c, L, nu, monke
         assert r.returncode == 0, r.stderr
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1]
+
+
+def test_full_size_513_known_answer_history():
+    """BASELINE's headline size (args 9 7 2 = 513^3, V(2,2)): the residual history printed by the unmodified
+    reference (six digits), the stopping cycle, and the final error against the analytic solution."""
+    known = [3.86147e+07, 4.68671e+06, 602953, 80775.4, 11126.2, 1563.03, 222.942, 32.2171, 4.71335, 0.698137,
+             0.104742, 0.0159273, 0.00245617, 0.00038423, 6.09488e-05, 9.8336e-06]
+    with M.Solver(9, 7, 2) as s:
+        s.setup_test_problem()
+        init = s.get_initial_residual()
+        norms = s.vcycles(16)
+        u = s.download(MG3D_U, 6)
+    for got, want in zip(norms, known):
+        assert got == pytest.approx(want, rel=2e-5)  # 6 printed digits; late cycles sit on the rounding floor
+    assert norms[15] <= 1e-8 * init < norms[14]      # test_mg_3d.c:31,40 stops after cycle 16
+    N = 513
+    g = np.arange(N) / (N - 1)
+    err = 0.0
+    for i in range(N):  # plane by plane: keeps the temporary small
+        exact = g[i] ** 2 - 2 * g[:, None] ** 2 + g[None, :] ** 2
+        err += float(((u[i * N * N:(i + 1) * N * N].reshape(N, N) - exact) ** 2).sum())
+    assert np.sqrt(err) == pytest.approx(4.48843e-09, rel=1e-3)
