@@ -113,6 +113,9 @@ struct mg3d_dist {
     ncclComm_t comm;
     bool have_comm;
     hipStream_t stream; /* every operation of every local rank is ordered on this one stream */
+    hipStream_t comm_stream; /* halo exchanges that overlap interior smoothing run here */
+    hipEvent_t ev_ready, ev_done;
+    bool overlap; /* MG3D_NO_OVERLAP=1 keeps every exchange on the compute stream */
     std::vector<RankState> rs;
     double *h_norms; /* pinned */
     double *d_norms; /* device: squared norms per cycle */
@@ -147,8 +150,16 @@ extern "C" int mg3d_dist_destroy(mg3d_dist *D)
 {
     if (!D)
         return MG3D_OK;
+    if (D->comm_stream)
+        (void)hipStreamSynchronize(D->comm_stream);
     if (D->stream)
         (void)hipStreamSynchronize(D->stream);
+    if (D->ev_ready)
+        (void)hipEventDestroy(D->ev_ready);
+    if (D->ev_done)
+        (void)hipEventDestroy(D->ev_done);
+    if (D->comm_stream)
+        (void)hipStreamDestroy(D->comm_stream);
     for (auto &R : D->rs) {
         for (auto &s : R.dl) {
             for (int k = 0; k < 3; k++)
@@ -200,6 +211,9 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
     D->have_comm = false;
     D->stream = nullptr;
     D->h_norms = D->d_norms = nullptr;
+    D->comm_stream = nullptr;
+    D->ev_ready = D->ev_done = nullptr;
+    D->overlap = !(getenv("MG3D_NO_OVERLAP") && getenv("MG3D_NO_OVERLAP")[0] == '1');
     if (D->ld >= num_levels) {
         delete D;
         return fail(MG3D_ERR_ARG, "mg3d_dist_create: %d ranks leave no level with >= 8 planes per rank", nranks);
@@ -274,6 +288,9 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
             DCHK(hipMemsetAsync(s.lv.alt, 0, s.lv.elems * sizeof(double), D->stream));
         }
     }
+    DCHK(hipStreamCreateWithFlags(&D->comm_stream, hipStreamNonBlocking));
+    DCHK(hipEventCreateWithFlags(&D->ev_ready, hipEventDisableTiming));
+    DCHK(hipEventCreateWithFlags(&D->ev_done, hipEventDisableTiming));
     D->norm_slots = 1024;
     DCHK(hipMalloc(&D->d_norms, sizeof(double) * D->norm_slots));
     DCHK(hipHostMalloc(&D->h_norms, sizeof(double) * D->norm_slots));
@@ -382,9 +399,8 @@ extern "C" int mg3d_dist_sync(mg3d_dist *D)
 
 /* --------------------------------------------------------------------------------------- transport */
 /* refresh the H halo planes of `field` on distributed level l from the neighbours' owned planes */
-static int exchange_halo(mg3d_dist *D, int field, int l)
+static int exchange_halo(mg3d_dist *D, int field, int l, hipStream_t s)
 {
-    hipStream_t s = D->stream;
     const int H = D->H;
     if (D->P == 1)
         return MG3D_OK;
@@ -481,38 +497,88 @@ static int reduce_norm(mg3d_dist *D, int slot)
 }
 
 /* ----------------------------------------------------------------------------------------- V-cycle */
-/* iters x two colour passes on a slab level, optional residual (2: store r, 1: norm only into the rank's
- * coarse->sumsq[0] over OWNED planes).  Same launch policy as the single-domain path. */
-static void slab_smooth_residual(mg3d_dist *D, RankState &R, int l, int post, int want_res,
-                                 const Geom *gc = nullptr, double *dc = nullptr, int ic_lo = -1, int ic_hi = -1)
+struct RestrictTarget { /* where a rank's restricted residual goes: coarse geometry, array, local planes */
+    const Geom *gc;
+    double *dc;
+    int lo, hi;
+};
+
+/* One smoothing stage on distributed level l for every local rank: iters x two colour passes, optional
+ * residual (want_res 2: r stored or restricted on the fly into tgt[], 1: norm only, over OWNED planes, into
+ * the rank's coarse->sumsq[0]).  Same launch policy as the single-domain path.
+ *
+ * xfield >= 0: the halo planes of that field (MG3D_U or MG3D_D) on this level must be refreshed from the
+ * neighbours first.  The exchange runs on the communication stream while the first sweep launch works on the
+ * interior planes [E, ni-E) -- those whose S-pass dependence cone (plus the pipeline's warm-up planes) does
+ * not reach a halo plane: E = H + S + 3 -- and the two end windows follow once the halos have arrived.
+ * All launches of the sweep read the same input and write disjoint planes of the alternate buffer. */
+static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const RestrictTarget *tgt, int xfield)
 {
-    SlabLevel &sl = SL(D, R, l);
-    Level &lv = sl.lv;
     hipStream_t s = D->stream;
-    mg3d_ctx *cx = R.coarse;
     const int c1 = post ? 0 : 1;
     int passes = 2 * D->nu;
-    bool done_res = want_res == 0;
+    bool done_res = want_res == 0, first = true;
     while (passes > 0 || !done_res) {
         const int S = passes >= 4 ? 4 : passes;
         const bool last = passes - S == 0;
         const bool res = last && want_res != 0 && S != 4;
-        const bool rst = res && dc != nullptr;
-        const int np = k_sweep(lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt,
-                               (res && want_res == 2 && !rst) ? lv.f[MG3D_R] : nullptr, res ? cx->partials : nullptr,
-                               MG3D_MAX_PARTIALS, lv.h, S, c1, res, s, sl.own_lo, sl.own_hi, rst ? gc : nullptr,
-                               rst ? dc : nullptr, ic_lo, ic_hi);
-        if (S > 0) {
-            double *t = lv.f[MG3D_U];
-            lv.f[MG3D_U] = lv.alt;
-            lv.alt = t;
+        bool split = false;
+        const int E = D->H + S + 3;
+        if (first && xfield >= 0) {
+            split = D->overlap && D->P > 1 && !res && S > 0;
+            for (auto &R : D->rs)
+                if (SL(D, R, l).lv.g.ni - 2 * E < 8)
+                    split = false;
+            if (split) {
+                HIPCHK(hipEventRecord(D->ev_ready, s));
+                HIPCHK(hipStreamWaitEvent(D->comm_stream, D->ev_ready, 0));
+                CHK(exchange_halo(D, xfield, l, D->comm_stream));
+                HIPCHK(hipEventRecord(D->ev_done, D->comm_stream));
+            } else {
+                CHK(exchange_halo(D, xfield, l, s));
+            }
         }
-        if (res) {
-            k_fold(cx->partials, np, cx->sumsq, s);
+        for (int phase = 0; phase < (split ? 2 : 1); phase++) {
+            if (split && phase == 1)
+                HIPCHK(hipStreamWaitEvent(s, D->ev_done, 0));
+            for (size_t ri = 0; ri < D->rs.size(); ri++) {
+                RankState &R = D->rs[ri];
+                SlabLevel &sl = SL(D, R, l);
+                Level &lv = sl.lv;
+                mg3d_ctx *cx = R.coarse;
+                const bool rst = res && tgt != nullptr && tgt[ri].dc != nullptr;
+                auto launch = [&](int i_lo, int i_hi) {
+                    return k_sweep(lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt,
+                                   (res && want_res == 2 && !rst) ? lv.f[MG3D_R] : nullptr, res ? cx->partials : nullptr,
+                                   MG3D_MAX_PARTIALS, lv.h, S, c1, res, s, sl.own_lo, sl.own_hi,
+                                   rst ? tgt[ri].gc : nullptr, rst ? tgt[ri].dc : nullptr, rst ? tgt[ri].lo : -1,
+                                   rst ? tgt[ri].hi : -1, nullptr, nullptr, i_lo, i_hi);
+                };
+                if (!split) {
+                    const int np = launch(-1, -1);
+                    if (res)
+                        k_fold(cx->partials, np, cx->sumsq, s);
+                } else if (phase == 0) {
+                    launch(E, lv.g.ni - E);
+                } else {
+                    launch(0, E);
+                    launch(lv.g.ni - E, lv.g.ni);
+                }
+            }
+        }
+        if (S > 0)
+            for (auto &R : D->rs) {
+                Level &lv = SL(D, R, l).lv;
+                double *t = lv.f[MG3D_U];
+                lv.f[MG3D_U] = lv.alt;
+                lv.alt = t;
+            }
+        if (res)
             done_res = true;
-        }
         passes -= S;
+        first = false;
     }
+    return MG3D_OK;
 }
 
 static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
@@ -522,37 +588,42 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
     for (auto &R : D->rs)
         if (!R.coarse->have_lu)
             return fail(MG3D_ERR_STATE, "mg3d_dist_vcycles: no coarse LU set (mg3d_dist_build_coarse)");
-    /* ---- down: distributed levels */
+    std::vector<RestrictTarget> tgt(D->rs.size());
+    /* ---- down: distributed levels.  On entry the halos of d (all levels: upload / previous restriction's
+     * exchange below) and of the finest u (pending: exchanged by the stage itself) are exact. */
     for (int l = L - 1; l >= ld; l--) {
-        for (auto &R : D->rs) {
+        for (size_t ri = 0; ri < D->rs.size(); ri++) {
+            RankState &R = D->rs[ri];
             SlabLevel &sl = SL(D, R, l);
             if (l < L - 1)
                 (void)hipMemsetAsync(sl.lv.f[MG3D_U], 0, sl.lv.elems * sizeof(double), s); /* mg_3d.h:1258 */
             /* owned coarse planes (plus the physical boundary planes at the ends of the domain) */
-            const Geom *gc;
-            double *dc;
-            int lo, hi;
+            RestrictTarget &t = tgt[ri];
             if (l - 1 >= ld) {
                 SlabLevel &sc = SL(D, R, l - 1);
-                gc = &sc.lv.g;
-                dc = sc.lv.f[MG3D_D];
-                lo = sc.own_lo;
-                hi = sc.own_hi;
+                t.gc = &sc.lv.g;
+                t.dc = sc.lv.f[MG3D_D];
+                t.lo = sc.own_lo;
+                t.hi = sc.own_hi;
             } else {
                 Level &lc = R.coarse->lv[ld - 1];
-                gc = &lc.g;
-                dc = lc.f[MG3D_D];
-                lo = R.rank == 0 ? 0 : sl.glo / 2;
-                hi = R.rank == D->P - 1 ? lc.g.N : sl.ghi / 2;
+                t.gc = &lc.g;
+                t.dc = lc.f[MG3D_D];
+                t.lo = R.rank == 0 ? 0 : sl.glo / 2;
+                t.hi = R.rank == D->P - 1 ? lc.g.N : sl.ghi / 2;
             }
-            const bool keep = R.coarse->keep_r;
-            /* :1282 + :1294 + :1310; interior of the coarse rhs on the fly unless r is to be kept */
-            slab_smooth_residual(D, R, l, 0, 2, keep ? nullptr : gc, keep ? nullptr : dc, lo, hi);
-            k_restrict(sl.lv.g, sl.lv.f[MG3D_R], *gc, dc, s, lo, hi, !keep);
         }
-        if (l - 1 >= ld)
-            CHK(exchange_halo(D, MG3D_D, l - 1));
-        else
+        const bool keep = D->rs[0].coarse->keep_r;
+        std::vector<RestrictTarget> none(D->rs.size(), RestrictTarget{nullptr, nullptr, -1, -1});
+        /* :1282 + :1294 + :1310 (interior of the coarse rhs on the fly unless r is to be kept).  Halos to
+         * refresh first: the finest u (left stale by the previous cycle's post-smoother) or, below, this
+         * level's d (just restricted: only owned planes were produced). */
+        CHK(stage_smooth(D, l, 0, 2, keep ? none.data() : tgt.data(), l == L - 1 ? MG3D_U : MG3D_D));
+        for (size_t ri = 0; ri < D->rs.size(); ri++) {
+            SlabLevel &sl = SL(D, D->rs[ri], l);
+            k_restrict(sl.lv.g, sl.lv.f[MG3D_R], *tgt[ri].gc, tgt[ri].dc, s, tgt[ri].lo, tgt[ri].hi, !keep);
+        }
+        if (l - 1 < ld)
             CHK(allgather_coarse_rhs(D));
     }
     /* ---- replicated levels: the ordinary V-cycle from level ld-1 (its guess zeroed first, :1258) */
@@ -576,18 +647,19 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
                 k_prolong(lc.g, lc.f[MG3D_U], sl.lv.g, sl.lv.f[MG3D_U], s, sl.own_lo, sl.own_hi);
             }
         }
-        CHK(exchange_halo(D, MG3D_U, l));
-        for (auto &R : D->rs)
-            slab_smooth_residual(D, R, l, 1, l == L - 1 ? 1 : 0); /* :1341 (+ :1354 at the top level) */
+        /* :1341 (+ :1354 at the top level); u halos (prolongated on owned planes only) refreshed first */
+        CHK(stage_smooth(D, l, 1, l == L - 1 ? 1 : 0, nullptr, MG3D_U));
     }
-    /* the next cycle (or a download of halo-inclusive data) starts from exact halos */
-    CHK(exchange_halo(D, MG3D_U, L - 1));
     CHK(reduce_norm(D, slot));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(MG3D_ERR_HIP, "mg3d_dist_vcycles: kernel launch failed: %s", hipGetErrorString(e));
     return MG3D_OK;
 }
+
+/* after the last cycle (and before any download of halo-inclusive data) the finest u halos are refreshed;
+ * inside a batch the next cycle's first stage does it, overlapped with its interior smoothing */
+static int dist_finish(mg3d_dist *D) { return exchange_halo(D, MG3D_U, D->L - 1, D->stream); }
 
 extern "C" int mg3d_dist_vcycles(mg3d_dist *D, int count, double *norms)
 {
@@ -597,6 +669,7 @@ extern "C" int mg3d_dist_vcycles(mg3d_dist *D, int count, double *norms)
         const int nb = (count - done < D->norm_slots) ? count - done : D->norm_slots;
         for (int c = 0; c < nb; c++)
             CHK(dist_enqueue_vcycle(D, c));
+        CHK(dist_finish(D));
         HIPCHK(hipMemcpyAsync(D->h_norms, D->d_norms, nb * sizeof(double), hipMemcpyDeviceToHost, D->stream));
         HIPCHK(hipStreamSynchronize(D->stream));
         if (norms)

@@ -62,7 +62,9 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
             interior of the coarse right-hand side dc (S = 0 or 2 with residual only) */,
             int ic_lo = -1, int ic_hi = -1 /* local coarse planes to write; default all */,
             const Geom *gce = nullptr, const double *ec = nullptr /* non-NULL: the input is vin + P(ec), the
-            trilinear prolongation of the coarse field ec (smoothing-only launches, S = 2 or 4) */);
+            trilinear prolongation of the coarse field ec (smoothing-only launches, S = 2 or 4) */,
+            int i_lo = -1, int i_hi = -1 /* local output planes of this launch; default all.  Several launches
+            with disjoint windows and the same vin/vout make up one sweep (overlap with halo exchange) */);
 /* b and x are level-0 grids in the padded layout g0; work holds 2n doubles */
 void k_lu_solve(const LuBand &lu, const Geom &g0, const double *b_pad, double *x_pad, double *work, hipStream_t s);
 

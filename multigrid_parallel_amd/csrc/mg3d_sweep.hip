@@ -56,6 +56,7 @@ struct SweepArgs {
     int c1;         /* colour of the first pass: 1 red, 0 black */
     int ntj, ntk;   /* tiles in j, k */
     int CI, nci;    /* planes per i-chunk, number of chunks */
+    int i_lo, i_hi;     /* local output planes this launch produces (chunks are cut from i_lo) */
     int acc_lo, acc_hi; /* local planes whose diff^2 enter the norm (owned planes of a slab) */
     /* fused prolongation (PRO): the level's input is vin + P(ec) (mg_3d.h:1000-1145); gce = geometry of ec */
     const double *ec;
@@ -151,7 +152,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     const int jt0 = tj * VJ - HJ, kt0 = tk * VK - HK;
     const int jrow0 = jt0 + w * RJ;
     const int kA = kt0 + 2 * lane; /* column 0 of the pair; column 1 = kA + 1 */
-    const int i_out0 = ci * a.CI, i_out1 = min(i_out0 + a.CI, g.ni);
+    const int i_out0 = a.i_lo + ci * a.CI, i_out1 = min(i_out0 + a.CI, a.i_hi);
     /* start plane: HI warm-up planes, one more if needed so that the column active at
      * local step p in row rr is (p + rr) & 1 */
     int i_s = i_out0 - HI;
@@ -525,7 +526,8 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
     /* i-chunk length: every chunk pays ST warm-up planes, but a level needs a few hundred blocks to keep
      * 256 CUs busy and short chunks mean fewer dependent steps.  Measured optimum on MI355X: about
      * 500-1000 blocks (513^3: CI 64-128, 257^3: 16, 129^3: 8, <= 65^3: 2-4). */
-    auto blocks = [&](int ci) { return (long long)a.ntj * a.ntk * ((g.ni + ci - 1) / ci); };
+    const int nout = a.i_hi - a.i_lo;
+    auto blocks = [&](int ci) { return (long long)a.ntj * a.ntk * ((nout + ci - 1) / ci); };
     int CI = RES == 2 ? 16 : 8; /* the fused restriction pays two more warm-up planes and two drain steps */
     const long long most = RES == 2 ? 1000 : Sh::ST <= 2 ? 1600 : 800; /* a short pipeline tolerates shorter chunks */
     while (CI < 128 && blocks(CI) > most)
@@ -534,10 +536,12 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
         CI /= 2;
     if (const char *e = getenv("MG3D_SWEEP_CI"))
         CI = atoi(e) > 0 ? atoi(e) : CI;
-    if (CI > g.ni)
-        CI = g.ni;
+    if (CI > nout)
+        CI = nout;
+    if (RES == 2 && (CI & 1))
+        CI += 1; /* chunk starts keep their parity relative to i_lo */
     a.CI = CI;
-    a.nci = (g.ni + CI - 1) / CI;
+    a.nci = (nout + CI - 1) / CI;
     /* measured on MI355X (513^3, S=4): the remap cuts L2 misses by 20 % but runs 5-10 % slower; off by default */
     a.xcd_remap = 0;
     if (const char *e = getenv("MG3D_XCD"))
@@ -618,9 +622,13 @@ template <> int dispatch<2, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
 
 int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
             int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo, int acc_hi,
-            const Geom *gc, double *dc, int ic_lo, int ic_hi, const Geom *gce, const double *ec)
+            const Geom *gc, double *dc, int ic_lo, int ic_hi, const Geom *gce, const double *ec, int i_lo, int i_hi)
 {
     SweepArgs a;
+    a.i_lo = i_lo >= 0 ? i_lo : 0;
+    a.i_hi = i_hi >= 0 ? i_hi : g.ni;
+    if (a.i_hi <= a.i_lo)
+        return 0;
     a.ec = ec;
     a.gce = gce ? *gce : g;
     a.dc = dc;
