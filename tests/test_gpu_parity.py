@@ -327,3 +327,41 @@ def test_full_size_513_known_answer_history():
         exact = g[i] ** 2 - 2 * g[:, None] ** 2 + g[None, :] ** 2
         err += float(((u[i * N * N:(i + 1) * N * N].reshape(N, N) - exact) ** 2).sum())
     assert np.sqrt(err) == pytest.approx(4.48843e-09, rel=1e-3)
+
+
+def test_smoother_only_loop_50_cubed():
+    """The smoother-only loop of test_rb_gs_3d.c:56-101 on 50^3 (N not of the form 2^k+1): one pre- and one
+    post-smoother sweep plus the residual norm per iteration, relative tolerance 1e-6.
+    Known answer: the reference's CURRENT operators (compiled unmodified, oracle/_ref) stop at iteration 1303
+    with 'Residual Norm: 0.28129  ResidRatio: 0.991804'.  The published note red_black_gs_scalability.txt:6-7
+    (652 / 0.280135 / 0.983675) was produced by an older state of the code and is not reproducible from the
+    reference tree (its driver no longer compiles; 0.991804^2 = 0.983675: that build evidently did twice the
+    smoothing per iteration).  The final field is also compared bit for bit with the oracle."""
+    N = 50
+    h = 1.0 / (N - 1)
+    u = np.zeros(N ** 3)
+    d = np.zeros(N ** 3)
+    M.lib().mg3d_fill_boundary_host(P(u), N, h)  # test_rb_gs_3d.c:34
+    with M.Solver(N, 1, 1) as s:  # a one-level context of 50^3 points
+        s.upload(MG3D_U, 0, u)
+        s.upload(MG3D_D, 0, d)
+        init = s.residual(0, store=False)  # :41
+        cmp_norm = init * 1e-6
+        norms = []
+        while True:
+            s.smooth(0, 0, 1)  # preSmoother(u,d,N,h,1)  :70
+            s.smooth(0, 1, 1)  # postSmoother(u,d,N,h,1) :71
+            norms.append(s.residual(0, store=False))
+            if not norms[-1] > cmp_norm or len(norms) > 2000:
+                break
+        got_u = s.download(MG3D_U, 0)
+    assert len(norms) == 1303
+    assert float(f"{norms[-1]:.6g}") == 0.28129
+    assert float(f"{norms[-1] / norms[-2]:.6g}") == 0.991804
+    assert float(f"{(norms[-1] / norms[-2]) ** 2:.6g}") == 0.983675
+    O.lib().orc_set_threads(4)
+    want = u.copy()
+    for _ in range(1303):
+        O.lib().orc_pre_smooth(O.P(want), O.P(d), N, h, 1)
+        O.lib().orc_post_smooth(O.P(want), O.P(d), N, h, 1)
+    assert np.array_equal(got_u, want)
