@@ -106,6 +106,13 @@ int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm);
 int mg3d_vcycle(mg3d_ctx *ctx, int level, double *norm);
 int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms);
 
+/* Full-multigrid initialisation, SolverFMGInitialize (mg_dirichlet_analytic.c:771-806; commented copy
+ * mg_3d.h:1364-1404): BCs on u[0], direct solve, then for every level prolong the coarser solution, impose the
+ * Dirichlet values BCFunc on the six faces (on the device), zero the coarser level, one V-cycle from that level. */
+int mg3d_fmg_initialize(mg3d_ctx *ctx);
+/* setupBoundaryConditions (mg_3d.h:1147-1239) on a device-resident field */
+int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level);
+
 /* per-stage timers (timing_info.h:6-47), filled from hipEvent pairs recorded in-stream (no stall).
  * on: 0 = off, 1 = every level, 2 = finest level only. */
 int mg3d_timing_enable(mg3d_ctx *ctx, int on);

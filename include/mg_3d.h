@@ -280,6 +280,22 @@ static inline double SolverLinSolve(void)
     return ret;
 }
 
+/* SolverFMGInitialize: live in mg_dirichlet_analytic.c:771-806, commented out in mg_3d.h:1364-1404 */
+static inline void SolverFMGInitialize(void)
+{
+    const int fin = numLevels - 1;
+    if (mg3d_host_newer_) {
+        for (int l = 0; l < numLevels; l++) { /* FMG reads d on every level and accumulates into every u */
+            mg3d_die_(mg3d_upload(mg3d_solver_ctx_, MG3D_U, l, u[l]), "SolverFMGInitialize");
+            mg3d_die_(mg3d_upload(mg3d_solver_ctx_, MG3D_D, l, d[l]), "SolverFMGInitialize");
+        }
+        mg3d_host_newer_ = 0;
+    }
+    mg3d_die_(mg3d_fmg_initialize(mg3d_solver_ctx_), "SolverFMGInitialize");
+    mg3d_device_newer_ = 1;
+    (void)fin;
+}
+
 static inline void SolverSmoothenEdgeValues(void)
 {
     mg3d_pull_();

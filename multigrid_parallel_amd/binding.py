@@ -56,6 +56,8 @@ SIGNATURES = {
     "mg3d_l2norm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
     "mg3d_vcycle": (C.c_int, [C.c_void_p, C.c_int, dp]),
     "mg3d_vcycles": (C.c_int, [C.c_void_p, C.c_int, dp]),
+    "mg3d_fmg_initialize": (C.c_int, [C.c_void_p]),
+    "mg3d_fill_boundary": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mg3d_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mg3d_timing_reset": (C.c_int, [C.c_void_p]),
     "mg3d_timing_get": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), dp]),
@@ -267,6 +269,12 @@ class Solver:
         norms = np.zeros(count)
         check(self.L.mg3d_vcycles(self._h, count, P(norms)))
         return norms
+
+    def fmg_initialize(self):
+        check(self.L.mg3d_fmg_initialize(self._h))
+
+    def fill_boundary(self, field, level):
+        check(self.L.mg3d_fill_boundary(self._h, field, level))
 
     # -- timing
     def timing_enable(self, on=True):

@@ -761,6 +761,34 @@ extern "C" int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms)
     return MG3D_OK;
 }
 
+/* -------------------------------------------------------------------- FMG */
+extern "C" int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level)
+{
+    CHK(check_field_level(ctx, field, level, "mg3d_fill_boundary"));
+    k_fill_boundary(ctx->lv[level].g, ctx->lv[level].f[field], ctx->lv[level].h, ctx->stream);
+    return launch_ok("mg3d_fill_boundary");
+}
+
+/* SolverFMGInitialize, mg_dirichlet_analytic.c:771-806 */
+extern "C" int mg3d_fmg_initialize(mg3d_ctx *ctx)
+{
+    if (!ctx)
+        return fail(MG3D_ERR_ARG, "mg3d_fmg_initialize: NULL context");
+    if (!ctx->have_lu)
+        return fail(MG3D_ERR_STATE, "mg3d_fmg_initialize: no coarse LU set");
+    hipStream_t s = ctx->stream;
+    k_fill_boundary(ctx->lv[0].g, ctx->lv[0].f[MG3D_U], ctx->lv[0].h, s);                                  /* :780 */
+    k_lu_solve(ctx->lu, ctx->lv[0].g, ctx->lv[0].f[MG3D_D], ctx->lv[0].f[MG3D_U], ctx->lu_work, s);         /* :783 */
+    for (int l = 1; l < ctx->L; l++) {
+        Level &lev = ctx->lv[l], &lc = ctx->lv[l - 1];
+        k_prolong(lc.g, lc.f[MG3D_U], lev.g, lev.f[MG3D_U], s);                                              /* :795 */
+        k_fill_boundary(lev.g, lev.f[MG3D_U], lev.h, s);                                                     /* :798 */
+        (void)hipMemsetAsync(lc.f[MG3D_U], 0, lc.elems * sizeof(double), s);                                 /* :801 */
+        CHK(mg3d_enqueue_vcycle(ctx, l, ctx->sumsq_slots - 1));                                              /* :804 */
+    }
+    return launch_ok("mg3d_fmg_initialize");
+}
+
 /* ------------------------------------------------------------------- timing */
 extern "C" int mg3d_timing_enable(mg3d_ctx *ctx, int on)
 {

@@ -49,6 +49,8 @@ void k_restrict(const Geom &gf, const double *r, const Geom &gc, double *dc, hip
                 int ic_hi = -1, bool faces_only = false /* injection on the coarse faces only */);
 void k_prolong(const Geom &gc, const double *ec, const Geom &gf, double *ef, hipStream_t s, int if_lo = -1,
                int if_hi = -1);
+/* BCFunc(i*h, j*h, k*h) = x*x - 2*y*y + z*z on the six faces of a field (mg_3d.h:89-90, 1147-1239) */
+void k_fill_boundary(const Geom &g, double *v, double h, hipStream_t s);
 /* folds np per-block partial sums, in a fixed order, into *out */
 void k_fold(const double *partials, int np, double *out, hipStream_t s);
 /* fused sweep (mg3d_sweep.hip): S colour passes starting with colour c1 (1 red, 0 black) from vin into

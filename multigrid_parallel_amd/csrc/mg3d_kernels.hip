@@ -57,6 +57,29 @@ void k_smooth_color(const Geom &g, double *v, const double *d, double hSq, int c
     hipLaunchKernelGGL(smooth_color_kernel, grid, block, 0, s, g, v, d, hSq, 1. / 6, color);
 }
 
+/* ------------------------------------------------------------ boundary fill
+ * setupBoundaryConditions, mg_3d.h:1147-1239: v = BCFunc(i*h, j*h, k*h) = ((x*x) - ((2*y)*y)) + (z*z) on
+ * every point of the six faces (mg_3d.h:89-90; same operation order as the C expression, no contraction). */
+__global__ void __launch_bounds__(256) fill_boundary_kernel(Geom g, double *__restrict__ v, double h)
+{
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    const int i = blockIdx.z;
+    if (k >= g.nk || j >= g.nj)
+        return;
+    const int ig = g.ig0 + i;
+    if (!(ig == 0 || ig == g.N - 1 || j == 0 || j == g.nj - 1 || k == 0 || k == g.nk - 1))
+        return;
+    const double x = ig * h, y = j * h, z = k * h;
+    v[gidx(g, i, j, k)] = x * x - 2 * y * y + z * z;
+}
+
+void k_fill_boundary(const Geom &g, double *v, double h, hipStream_t s)
+{
+    dim3 grid((g.nk + 63) / 64, (g.nj + 3) / 4, g.ni);
+    hipLaunchKernelGGL(fill_boundary_kernel, grid, dim3(64, 4, 1), 0, s, g, v, h);
+}
+
 /* ------------------------------------------------------------- block reduce */
 __device__ __forceinline__ double wave_sum(double x)
 {

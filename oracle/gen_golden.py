@@ -187,6 +187,38 @@ def main():
         vc[f"usha_{key}"] = np.frombuffer(bytes.fromhex(digest(lv[L - 1])), dtype=np.uint8)
         vc[f"usample_{key}"] = lv[L - 1][::97].copy()
         print(key, norms)
+    # ---- SolverFMGInitialize (spec: mg_dirichlet_analytic.c:771-806 / commented mg_3d.h:1364-1404) replayed with
+    # the reference's own operators on the test_mg_3d.c problem, followed by three V-cycles
+    for (c, L, nu) in ((5, 4, 2), (3, 5, 1)):
+        argv = (C.c_char_p * 4)(b"ref", str(c).encode(), str(L).encode(), str(nu).encode())
+        lib.SolverInitialize(4, argv)
+        N = (c - 1) * (1 << (L - 1)) + 1
+        h = 1.0 / (N - 1)
+        lv = [np.zeros(((c - 1) * (1 << l) + 1) ** 3) for l in range(L)]
+        lf = [np.zeros_like(a) for a in lv]
+        lr = [np.zeros_like(a) for a in lv]
+        arr = lambda xs: (dp * L)(*[P(a) for a in xs])
+        n0 = c ** 3
+        A = np.zeros(n0 * n0)
+        lib.constructCoarseMatrixA(P(A), c, h * (1 << (L - 1)))
+        lib.convertToLU_InPlace(P(A), n0)
+        lib.setupBoundaryConditions(P(lf[L - 1]), N, h)
+        lib.setupBoundaryConditions(P(lv[L - 1]), N, h)
+        U, F, R = arr(lv), arr(lf), arr(lr)
+        Nl, hl = c, 1.0 / (c - 1)
+        lib.setupBoundaryConditions(P(lv[0]), Nl, hl)           # :780
+        lib.solveWithLU(P(A), n0, P(lf[0]), P(lv[0]))            # :783
+        for l in range(1, L):
+            Nc, Nl, hl = Nl, 2 * Nl - 1, hl * 0.5
+            lib.prolongateAndCorrectError(P(lv[l - 1]), Nc, P(lv[l]), Nl)   # :795
+            lib.setupBoundaryConditions(P(lv[l]), Nl, hl)                    # :798
+            lv[l - 1][:] = 0.0                                               # :801
+            lib.vcycle(U, F, R, hl, l, L, nu, Nl, P(A))                      # :804
+        key = f"fmg_{c}_{L}_{nu}"
+        vc[f"u0_{key}"] = lv[L - 1].copy()
+        vc[f"norms_{key}"] = np.array([lib.vcycle(U, F, R, h, L - 1, L, nu, N, P(A)) for _ in range(3)])
+        vc[f"u_{key}"] = lv[L - 1].copy()
+        print(key, vc[f"norms_{key}"])
     np.savez_compressed(os.path.join(OUT, "vcycle.npz"), **vc)
     for f in ("operators.npz", "vcycle.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")

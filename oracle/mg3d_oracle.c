@@ -291,6 +291,24 @@ double orc_vcycle(double **u, double **f, double **res, double h, int q, int num
     return orc_residual(v, f[q], N, h, NULL);    /* :1354 */
 }
 
+void orc_fmg_initialize(double **u, double **d, double **r, int c, int numLevels, int iters, double grid_length,
+                        const double *LU)
+{
+    int N = c;
+    double h = grid_length / (c - 1);            /* mg_dirichlet_analytic.c:779 */
+    orc_fill_boundary(u[0], N, h);               /* :780 */
+    orc_lu_solve(LU, N * N * N, d[0], u[0]);     /* :783 */
+    for (int l = 1; l < numLevels; l++) {
+        const int Nc = N;
+        N = 2 * N - 1;                           /* :790 */
+        h = h * 0.5;                             /* :791 */
+        orc_prolong(u[l - 1], Nc, u[l], N);      /* :795 */
+        orc_fill_boundary(u[l], N, h);           /* :798 */
+        memset(u[l - 1], 0, sizeof(double) * (size_t)Nc * Nc * Nc); /* :801 */
+        orc_vcycle(u, d, r, h, l, numLevels, iters, N, LU);         /* :804 */
+    }
+}
+
 static double **alloc_levels(int c, int L) /* mg_3d.h:30-48 */
 {
     double **a = (double **)malloc(sizeof(double *) * (size_t)L);

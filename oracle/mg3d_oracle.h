@@ -60,6 +60,13 @@ double orc_l2norm(const double *d, long n);
 double orc_vcycle(double **u, double **f, double **res, double h, int q,
                   int numLevels, int iters, int N, const double *LU);
 
+/* SolverFMGInitialize as specified by mg_dirichlet_analytic.c:771-806 (commented copy mg_3d.h:1364-1404):
+ * BCs on u[0], direct solve, then per level: prolong the coarser solution into u[l], impose the BCs, zero
+ * u[l-1], one V-cycle from level l.  (As in the reference, a V-cycle started below the finest level zeroes
+ * its own guess first, mg_3d.h:1258.)  Every step is one of the pinned operators above. */
+void orc_fmg_initialize(double **u, double **d, double **r, int c, int numLevels, int iters, double grid_length,
+                        const double *LU);
+
 /* Convenience driver used by tests and by bench.py's cpu_baseline leg:
  * sets up the reference's test problem (test_mg_3d.c:11-33: BC values into
  * the faces of both d and u on the finest level, interior zero), runs

@@ -38,6 +38,7 @@ def lib():
         L.orc_l2norm.argtypes = [dp, C.c_long]
         L.orc_vcycle.restype = C.c_double
         L.orc_vcycle.argtypes = [C.POINTER(dp)] * 3 + [C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+        L.orc_fmg_initialize.argtypes = [C.POINTER(dp)] * 3 + [C.c_int, C.c_int, C.c_int, C.c_double, dp]
         L.orc_run_problem.restype = C.c_double
         L.orc_run_problem.argtypes = [C.c_int] * 5 + [dp, dp, dp]
         L.orc_max_threads.restype = C.c_int

@@ -365,3 +365,41 @@ def test_smoother_only_loop_50_cubed():
         O.lib().orc_pre_smooth(O.P(want), O.P(d), N, h, 1)
         O.lib().orc_post_smooth(O.P(want), O.P(d), N, h, 1)
     assert np.array_equal(got_u, want)
+
+
+@pytest.mark.parametrize("c,L,nu", [(5, 4, 2), (3, 5, 1), (9, 4, 2)])
+def test_fmg_initialize_matches_oracle_and_golden(c, L, nu):
+    H = O.Hierarchy(c, L)
+    N, h = H.N[-1], 1.0 / (H.N[-1] - 1)
+    n0 = c ** 3
+    LU = np.zeros(n0 * n0)
+    O.lib().orc_coarse_matrix(O.P(LU), c, h * (1 << (L - 1)))
+    O.lib().orc_lu_factor(O.P(LU), n0)
+    O.lib().orc_fill_boundary(O.P(H.d[-1]), N, h)
+    O.lib().orc_fill_boundary(O.P(H.u[-1]), N, h)
+    O.lib().orc_set_threads(1)
+    O.lib().orc_fmg_initialize(H.ptrs(H.u), H.ptrs(H.d), H.ptrs(H.r), c, L, nu, 1.0, O.P(LU))
+    with M.Solver(c, L, nu) as s:
+        s.setup_test_problem()
+        s.fmg_initialize()
+        for l in range(L):
+            assert np.array_equal(s.download(MG3D_U, l), H.u[l]), f"u level {l}"
+        norms = s.vcycles(3)
+        u = s.download(MG3D_U, L - 1)
+    want = [O.lib().orc_vcycle(H.ptrs(H.u), H.ptrs(H.d), H.ptrs(H.r), h, L - 1, L, nu, N, O.P(LU)) for _ in range(3)]
+    np.testing.assert_allclose(norms, want, rtol=norm_rtol(N))
+    assert np.array_equal(u, H.u[-1])
+    key = f"fmg_{c}_{L}_{nu}"
+    if f"u_{key}" in V:
+        assert np.array_equal(u, V[f"u_{key}"])
+
+
+@pytest.mark.parametrize("N", [5, 9, 33])
+def test_device_boundary_fill_matches_host(N):
+    with M.Solver(N, 1, 1) as s:
+        v = rnd(N ** 3, N)
+        s.upload(MG3D_U, 0, v)
+        s.fill_boundary(MG3D_U, 0)
+        want = v.copy()
+        M.lib().mg3d_fill_boundary_host(P(want), N, 1.0 / (N - 1))
+        assert np.array_equal(s.download(MG3D_U, 0), want)

@@ -159,3 +159,22 @@ def test_thread_count_invariance():
     n1, u1, _, _ = O.run_problem(5, 4, 2, 6)
     assert np.array_equal(u1, u4)
     np.testing.assert_allclose(n1, n4, rtol=1e-13)
+
+
+@pytest.mark.parametrize("c,L,nu", [(5, 4, 2), (3, 5, 1)])
+def test_fmg_initialize_bit_exact(c, L, nu):
+    """SolverFMGInitialize (spec mg_dirichlet_analytic.c:771-806) replayed with the reference's own operators."""
+    key = f"fmg_{c}_{L}_{nu}"
+    H = O.Hierarchy(c, L)
+    N, h = H.N[-1], 1.0 / (H.N[-1] - 1)
+    n0 = c ** 3
+    LU = np.zeros(n0 * n0)
+    O.lib().orc_coarse_matrix(O.P(LU), c, h * (1 << (L - 1)))
+    O.lib().orc_lu_factor(O.P(LU), n0)
+    O.lib().orc_fill_boundary(O.P(H.d[-1]), N, h)
+    O.lib().orc_fill_boundary(O.P(H.u[-1]), N, h)
+    O.lib().orc_fmg_initialize(H.ptrs(H.u), H.ptrs(H.d), H.ptrs(H.r), c, L, nu, 1.0, O.P(LU))
+    assert np.array_equal(H.u[-1], V[f"u0_{key}"])
+    norms = [O.lib().orc_vcycle(H.ptrs(H.u), H.ptrs(H.d), H.ptrs(H.r), h, L - 1, L, nu, N, O.P(LU)) for _ in range(3)]
+    assert np.array_equal(np.array(norms), V[f"norms_{key}"])
+    assert np.array_equal(H.u[-1], V[f"u_{key}"])
