@@ -403,3 +403,46 @@ def test_device_boundary_fill_matches_host(N):
         want = v.copy()
         M.lib().mg3d_fill_boundary_host(P(want), N, 1.0 / (N - 1))
         assert np.array_equal(s.download(MG3D_U, 0), want)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3])
+def test_degenerate_sizes_are_no_ops_or_match_oracle(N):
+    """Grids with an empty interior (N = 1, 2) leave every array untouched and give a zero norm, as the reference's
+    loops (1 .. N-2) do; N = 3 has a single interior point."""
+    h = 0.5
+    v, d = rnd(N ** 3, 5), rnd(N ** 3, 6)
+    got, want = v.copy(), v.copy()
+    check(M.lib().mg3d_host_smooth(P(got), P(d), N, h, 2, 0))
+    O.lib().orc_pre_smooth(O.P(want), O.P(d), N, h, 2)
+    assert np.array_equal(got, want)
+    res_g, res_w = np.full(N ** 3, 1.5), np.full(N ** 3, 1.5)
+    gn = C.c_double(-1)
+    check(M.lib().mg3d_host_residual(P(got), P(d), N, h, P(res_g), C.byref(gn)))
+    O.lib().orc_set_threads(1)
+    wn = O.lib().orc_residual(O.P(want), O.P(d), N, h, O.P(res_w))
+    assert np.array_equal(res_g, res_w) and gn.value == pytest.approx(wn, rel=1e-14, abs=0)
+    if N < 3:
+        assert gn.value == 0.0 and np.array_equal(got, v)
+
+
+def test_zero_smoothing_iterations_and_single_level():
+    """nu = 0 (the V-cycle degenerates to residual / restrict / solve / prolong) and a one-level hierarchy
+    (vcycle at q = 0 is the direct solve and returns 0, mg_3d.h:1262-1277)."""
+    O.lib().orc_set_threads(1)
+    want_norms, want_u, _, _ = O.run_problem(5, 3, 0, 3)
+    with M.Solver(5, 3, 0) as s:
+        s.setup_test_problem()
+        got = s.vcycles(3)
+        assert np.array_equal(s.download(MG3D_U, 2), want_u)
+    np.testing.assert_allclose(got, want_norms, rtol=1e-12)
+    with M.Solver(5, 1, 2) as s:
+        s.get_details()
+        b = rnd(125, 9)
+        s.upload(MG3D_D, 0, b)
+        assert s.vcycle(0) == 0.0
+        LU = np.zeros(125 * 125)
+        O.lib().orc_coarse_matrix(O.P(LU), 5, s.h)
+        O.lib().orc_lu_factor(O.P(LU), 125)
+        x = np.zeros(125)
+        O.lib().orc_lu_solve(O.P(LU), 125, O.P(b), O.P(x))
+        assert np.array_equal(s.download(MG3D_U, 0), x)
