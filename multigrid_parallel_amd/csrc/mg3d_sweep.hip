@@ -1,42 +1,36 @@
 /*
  * mg3d_sweep.hip -- the fused, temporally blocked red-black Gauss-Seidel kernel.
  *
- * One launch streams a level ONCE through the chip and applies S consecutive
- * colour passes (S = 2*nu: red,black,red,black for the pre-smoother,
- * black,red,... for the post-smoother; mg_3d.h:640-781) and, optionally, the
- * residual (mg_3d.h:794-842; r store and/or the L2 norm) on the smoothed field:
- *      reads v, d once  ->  writes v' (and r) once.
- * The separate-pass formulation moves 6*n*w bytes per RB sweep; this one moves
- * 3*n*w for any number of fused sweeps.
+ * One launch streams a level ONCE through the chip and applies S consecutive colour passes (S = 2*nu:
+ * red,black,red,black for the pre-smoother, black,red,... for the post-smoother; mg_3d.h:640-781) and,
+ * optionally, the residual of the result (mg_3d.h:794-842: r store and/or the L2 norm), optionally the
+ * full-weighting restriction of that residual into the coarse right-hand side (mg_3d.h:961-995; r then
+ * never travels to HBM), optionally the trilinear prolongation of the coarse correction into its input
+ * (mg_3d.h:1000-1145):      reads v, d once  ->  writes v' (and r or d_coarse) once.
+ * The separate-pass formulation moves 6*n*w bytes per RB sweep; this one moves 3*n*w for any number of
+ * fused sweeps.
  *
- * Every grid value is bit-identical to the reference: a colour pass only reads
- * the other colour, so the result of a pass does not depend on traversal order,
- * and each update evaluates the reference's expression (mg_3d.h:438-443)
- * with the same association and no FMA contraction.
+ * Every grid value is bit-identical to the reference: a colour pass only reads the other colour, so the
+ * result of a pass does not depend on traversal order, and each update evaluates the reference's
+ * expression (mg_3d.h:438-443) with the same association and no FMA contraction.
  *
- * ---- pipeline --------------------------------------------------------------
- * A block owns a (j,k) tile and marches along i (planes of NJ x NK points).
- * "Stage s" (s = 1..ST) is the s-th colour pass (or, for s > S, one half of the
- * residual); at step p (plane p just loaded) stage s works on plane p-s.
- * A point of plane q has colour (q+j+k)&1, hence column (j,k) is touched by
- * stage s at step p iff (p+j+k) == c1+1 (mod 2) -- independent of s: at each
- * step exactly one column of every k-pair is active, and it runs ALL stages
- * (on planes p-1 .. p-ST).  Stage s needs from stage s-1:
+ * ---- pipeline --------------------------------------------------------------------------------------------
+ * A block owns a (j,k) tile and marches along i (planes of NJ x NK points).  "Stage s" (s = 1..ST) is the
+ * s-th colour pass (or, for s > S, the residual-only gather); at step p (plane p just loaded) stage s works
+ * on plane p-s.  A point of plane q has colour (q+j+k)&1, hence column (j,k) is touched by stage s at step p
+ * iff (p+j+k) == c1+1 (mod 2) -- independent of s: at each step exactly one column of every k-pair is
+ * active, and it runs ALL stages (on planes p-1 .. p-ST).  Stage s needs from stage s-1:
  *      i-1, i+1 : the thread's own column, two steps ago / this step (registers)
- *      j-1, j+1 : the inactive column of the rows above/below, produced one
- *                 step ago (registers: a thread owns RJ consecutive rows;
- *                 LDS for the rows of the neighbouring wave)
- *      k-1, k+1 : the pair partner (own register) and the neighbour lane's
- *                 partner (one cross-lane move)
- * so the whole window lives in registers; LDS only carries one row per wave
- * edge and stage, and there is ONE barrier per plane.
+ *      j-1, j+1 : the inactive column of the rows above/below, produced one step ago (registers: a thread
+ *                 owns RJ consecutive rows; LDS for the rows of the neighbouring wave)
+ *      k-1, k+1 : the pair partner (own register) and the neighbour lane's partner (one DPP move)
+ * so the whole temporal window lives in registers; LDS only carries one row per wave edge and stage, and
+ * there is ONE barrier per plane.
  *
- * Geometry: a wave covers 64 k-pairs = 128 consecutive k; NW waves are stacked
- * in j, each thread holding RJ rows: tile = (NW*RJ) x 128 points including a
- * halo of H = S (+1 with residual) points on every side that is recomputed
- * redundantly (halo loads hit L2: neighbouring tiles run on the same XCD).
- * The i range is cut into chunks with ST warm-up planes each.  Output goes to a
- * second array (the halo makes an in-place update racy between tiles).
+ * Geometry: a wave covers 64 k-pairs = 128 consecutive k; NW waves are stacked in j, each thread holding RJ
+ * rows: tile = (NW*RJ) x 128 points including a halo of H = S (+1 with residual, +2 with restriction)
+ * points on every side that is recomputed redundantly.  The i range is cut into chunks with H warm-up
+ * planes each.  Output goes to a second array (the halo makes an in-place update racy between tiles).
  */
 #include "mg3d_internal.h"
 
@@ -342,8 +336,6 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 
 #pragma unroll
         for (int rr = 0; rr < RJ; rr++) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int X = (PAR + rr) & 1; /* active column of this row at this step */
             double nw[STX + 1];
             nw[0] = X ? cur_v[rr].y : cur_v[rr].x;
