@@ -527,7 +527,7 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
         if (first && xfield >= 0) {
             split = D->overlap && D->P > 1 && !res && S > 0;
             for (auto &R : D->rs)
-                if (SL(D, R, l).lv.g.ni - 2 * E < 8)
+                if (SL(D, R, l).lv.g.ni - 2 * E < 24) /* too thin: three launches would cost more than they hide */
                     split = false;
             if (split) {
                 HIPCHK(hipEventRecord(D->ev_ready, s));

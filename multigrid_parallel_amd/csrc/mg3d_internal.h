@@ -36,7 +36,7 @@ struct LuBand {
     double *urot; /* [n][64*rot_r] */
 };
 
-#define MG3D_MAX_PARTIALS 8192
+#define MG3D_MAX_PARTIALS 32768
 
 /* launchers (mg3d_kernels.hip); all asynchronous on `s` */
 void k_smooth_color(const Geom &g, double *v, const double *d, double hSq, int color, hipStream_t s);

@@ -528,6 +528,8 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
         CI /= 2;
     if (const char *e = getenv("MG3D_SWEEP_CI"))
         CI = atoi(e) > 0 ? atoi(e) : CI;
+    while (a.partials && blocks(CI) + 8 > max_partials && CI < nout)
+        CI *= 2; /* one partial sum per block must fit the caller's buffer */
     if (CI > nout)
         CI = nout;
     if (RES == 2 && (CI & 1))
