@@ -76,13 +76,14 @@ template <int S, int RES> struct SweepShape {
 };
 
 /* One-lane shifts across the whole wave as DPP moves (v_mov_b32_dpp wave_shr:1 / wave_shl:1, two per
- * double): VALU-rate, no LDS crossbar.  Lane 0 / lane 63 keep their own value (tile halo, never used). */
+ * double): VALU-rate, no LDS crossbar.  Lane 0 / lane 63 have no source and read 0 (tile halo, never used). */
 template <int CTRL> __device__ __forceinline__ double dpp_move(double x)
 {
     const long long b = __double_as_longlong(x);
     const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-    const int rlo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    const int rhi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    /* bound_ctrl: the lane without a source (0 or 63, a tile-halo lane) reads 0; no copy of the old value */
+    const int rlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    const int rhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __longlong_as_double(((long long)rhi << 32) | (unsigned int)rlo);
 }
 __device__ __forceinline__ double lane_from_left(double x) /* lane l receives lane l-1 */
