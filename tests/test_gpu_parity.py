@@ -446,3 +446,27 @@ def test_zero_smoothing_iterations_and_single_level():
         x = np.zeros(125)
         O.lib().orc_lu_solve(O.P(LU), 125, O.P(b), O.P(x))
         assert np.array_equal(s.download(MG3D_U, 0), x)
+
+
+def test_host_vcycle_started_below_the_finest_level():
+    """vcycle(u,f,res,h,q,...) with q < numLevels-1 zeroes its own guess first (mg_3d.h:1254-1260), which is how the
+    FMG driver calls it; caller-owned hierarchies, every level copied back."""
+    c, L, nu, q = 5, 4, 2, 2
+    H, G_ = O.Hierarchy(c, L), O.Hierarchy(c, L)
+    Nq = H.N[q]
+    hq = 1.0 / (H.N[-1] - 1) * (1 << (L - 1 - q))
+    n0 = c ** 3
+    LU = np.zeros(n0 * n0)
+    O.lib().orc_coarse_matrix(O.P(LU), c, hq * (1 << q))
+    O.lib().orc_lu_factor(O.P(LU), n0)
+    for X in (H, G_):
+        X.u[q][:] = rnd(Nq ** 3, 1)  # must be wiped by the cycle
+        X.d[q][:] = rnd(Nq ** 3, 2)
+    O.lib().orc_set_threads(1)
+    wn = O.lib().orc_vcycle(H.ptrs(H.u), H.ptrs(H.d), H.ptrs(H.r), hq, q, L, nu, Nq, O.P(LU))
+    gn = C.c_double(0)
+    check(M.lib().mg3d_host_vcycle(G_.ptrs(G_.u), G_.ptrs(G_.d), G_.ptrs(G_.r), hq, q, L, nu, Nq, P(LU), C.byref(gn),
+                                   None, None))
+    assert gn.value == pytest.approx(wn, rel=norm_rtol(Nq))
+    for l in range(q + 1):
+        assert np.array_equal(G_.u[l], H.u[l]) and np.array_equal(G_.d[l], H.d[l]) and np.array_equal(G_.r[l], H.r[l])
