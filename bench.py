@@ -81,7 +81,15 @@ def cpu_child(args):
         kind = "port"
     N = (args.coarse - 1) * (1 << (args.levels - 1)) + 1
     per = secs / (cycles + 1)
-    print(json.dumps({"value": 1.0 / per, "unit": "V-cycles/s", "cores": cores, "kind": kind,
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    print(json.dumps({"value": 1.0 / per, "unit": "V-cycles/s", "cores": cores, "kind": kind, "cpu": model,
                       "sample": f"{cycles + 1} consecutive V({args.nu},{args.nu}) cycles of the same {N}^3 problem "
                                 f"(args {args.coarse} {args.levels} {args.nu}), OpenMP on {cores} host cores (this GPU's CPU share), "
                                 f"omp_get_wtime around the cycle loop as test_mg_3d.c:36,68",
@@ -98,7 +106,14 @@ def run_cpu_baseline(args):
         cmd.append("--cpu-port")
     try:
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-        return json.loads(out.stdout.strip().splitlines()[-1])
+        res = json.loads(out.stdout.strip().splitlines()[-1])
+        if cores > 8:  # also at 8 threads, the thread count of the reference's own scaling note
+            env8 = dict(env, OMP_NUM_THREADS="8")
+            cmd8 = [x for x in cmd]
+            cmd8[cmd8.index("--cpu-cycles") + 1] = str(max(2, args.cpu_cycles // 2))
+            out8 = subprocess.run(cmd8, env=env8, capture_output=True, text=True, timeout=900)
+            res["value_8_threads"] = json.loads(out8.stdout.strip().splitlines()[-1])["value"]
+        return res
     except Exception as e:  # the baseline is reported, never required
         return {"value": None, "unit": "V-cycles/s", "cores": cores, "kind": "port", "sample": f"failed: {e}"}
 
@@ -196,7 +211,7 @@ def main():
     solver.setup_test_problem()
     init = solver.get_initial_residual()
 
-    solver.vcycles(args.warmup)
+    warm_norms = solver.vcycles(args.warmup)
     solver.timing_reset()
     solver.timing_enable(1 if args.breakdown else 2)  # event pairs around the finest-level stages only; no host stall
     barrier(solver)
@@ -244,6 +259,28 @@ def main():
         except Exception:
             pass
 
+    # on-box ceiling of the memory system: device-to-device copy of 1 GiB (read + write), best of 5
+    copy_gbs = None
+    try:
+        src = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+        dst = torch.empty_like(src)
+        best = 1e9
+        for _ in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dst.copy_(src)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        copy_gbs = 2 * src.numel() * 8 / (best * 1e-3) / 1e9
+        del src, dst
+    except Exception:
+        pass
+    roof["measured_copy_gbs"] = copy_gbs
+    roof["frac_of_measured_copy"] = (achieved / copy_gbs) if copy_gbs else None
+    hist = list(warm_norms) + list(norms)
+    to_tol = next((i + 1 for i, x in enumerate(hist) if x <= 1e-8 * init), None)
+
     if rank == 0:
         alg = algorithmic_bytes_per_cycle(c, L, nu)
         per_step = elapsed / args.steps
@@ -260,6 +297,7 @@ def main():
             "vcycle_frac_of_hbm_peak": alg / per_step / 1e9 / HBM_PEAK_GBS,
             "smoother_hbm_gbs": 3.0 * n_f * 8 * nu / (sm_secs / max(1, sm_calls)) / 1e9 if sm_secs > 0 else None,
             "first_norm": float(norms[0]), "last_norm": float(norms[-1]), "initial_rhs_norm": init,
+            "cycles_to_1e-8": to_tol,  # test_mg_3d.c stopping rule; the reference needs 16 at 513^3
             "roofline": roof,
         }
         if args.breakdown:
