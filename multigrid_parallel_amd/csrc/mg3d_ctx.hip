@@ -503,7 +503,8 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
             /* the residual rides on a 2-pass launch; behind 4 passes it gets its own launch (the 5-stage
              * window leaves too few registers for a tile with a useful interior: measured 1.9 ms fused
              * against 0.85 + 0.76 ms split on a 513^3 level) */
-            const bool res = last && want_res != 0 && S != 4;
+            static const bool res4 = getenv("MG3D_FUSE_RES4") && getenv("MG3D_FUSE_RES4")[0] == '1'; /* experiment */
+            const bool res = last && want_res != 0 && (S != 4 || (res4 && coarse == nullptr));
             const bool rst = res && coarse != nullptr;
             const bool with_pro = pro != nullptr && passes == 2 * iters; /* first launch only */
             int np;

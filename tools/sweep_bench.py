@@ -35,6 +35,8 @@ def timeit(fn, reps=reps):
 cases = {
     "S4RES": (lambda: s.smooth_residual(lev, 0, 2, True, False), (6 + 3) * n * 8,
               ["6,4,1", "6,4,2", "4,4,2", "4,8,1", "2,8,2"]),
+    "S4NORM": (lambda: s.smooth_residual(lev, 1, 2, False, False), (6 + 2) * n * 8,
+               ["6,4,1", "6,4,2", "4,4,2", "4,8,1", "2,8,2"]),
     "S4": (lambda: s.smooth(lev, 0, 2), 6 * n * 8, ["8,4,1", "8,4,2", "6,4,2", "4,8,1"]),
     "S2RES": (lambda: s.smooth_residual(lev, 0, 1, True, False), (3 + 3) * n * 8, ["4,8,1", "8,4,2", "6,4,2"]),
     "S2": (lambda: s.smooth(lev, 0, 1), 3 * n * 8, ["6,8,1", "8,4,2", "4,8,1"]),
