@@ -243,9 +243,51 @@ __global__ void __launch_bounds__(256) restrict_kernel(Geom gf, const double *__
     dc[gidx(gc, ic, jc, kc)] = val;
 }
 
+/* injection on the six coarse faces only (mg_3d.h:879-958): one thread per face point.
+ * blockIdx.z = face: 0/1 the physical i-faces, 2/3 the j-faces, 4/5 the k-faces */
+__global__ void __launch_bounds__(256) restrict_faces_kernel(Geom gf, const double *__restrict__ r, Geom gc,
+                                                             double *__restrict__ dc, int ic_lo, int ic_hi)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x, a = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
+    int ic, jc, kc;
+    if (f < 2) {
+        const int icg = f == 0 ? 0 : gc.N - 1;
+        ic = icg - gc.ig0;
+        jc = a;
+        kc = b;
+        if (ic < ic_lo || ic >= ic_hi || jc >= gc.nj || kc >= gc.nk)
+            return;
+    } else if (f < 4) {
+        ic = ic_lo + a;
+        jc = f == 2 ? 0 : gc.nj - 1;
+        kc = b;
+        if (ic >= ic_hi || kc >= gc.nk)
+            return;
+    } else {
+        ic = ic_lo + a;
+        jc = b;
+        kc = f == 4 ? 0 : gc.nk - 1;
+        if (ic >= ic_hi || jc >= gc.nj)
+            return;
+    }
+    const int fi = 2 * (gc.ig0 + ic) - gf.ig0;
+    dc[gidx(gc, ic, jc, kc)] = r[gidx(gf, fi, 2 * jc, 2 * kc)];
+}
+
 void k_restrict(const Geom &gf, const double *r, const Geom &gc, double *dc, hipStream_t s, int ic_lo, int ic_hi,
                 bool faces_only)
 {
+    if (faces_only) {
+        const int lo = ic_lo >= 0 ? ic_lo : ((gc.ig0 == 0) ? 0 : 1);
+        const int hi = ic_hi >= 0 ? ic_hi : ((gc.ig0 + gc.ni == gc.N) ? gc.ni : gc.ni - 1);
+        if (hi <= lo)
+            return;
+        const int m = max(max(gc.nj, gc.nk), hi - lo);
+        dim3 grid((m + 63) / 64, (m + 3) / 4, 6);
+        hipLaunchKernelGGL(restrict_faces_kernel, grid, dim3(64, 4, 1), 0, s, gf, r, gc, dc, lo, hi);
+        return;
+    }
+
     /* local coarse planes written: physical boundary planes and owned planes; a
      * halo plane (local 0 / ni-1 that is not a physical boundary) is the neighbour's */
     const int lo = ic_lo >= 0 ? ic_lo : ((gc.ig0 == 0) ? 0 : 1);
