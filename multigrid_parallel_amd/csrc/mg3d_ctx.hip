@@ -485,8 +485,10 @@ static int read_norm(mg3d_ctx *ctx, int slot, double *norm)
  * alternate buffer; the residual rides on the last launch.  want_res: 0 none, 1 norm only,
  * 2 store r (+ norm).  The squared norm goes to sumsq[slot]. */
 static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters, int want_res, int slot,
-                                    Level *coarse = nullptr, const Level *pro = nullptr)
+                                    Level *coarse = nullptr, const Level *pro = nullptr, bool zero_in = false)
 {
+    /* zero_in: u of this level is to be taken as identically zero (the memset of mg_3d.h:1258-1259 folded
+     * into the first launch: it neither reads u nor needs it zeroed); only valid when a launch with S > 0 follows */
     /* pro != NULL: the smoother's input is u + P(pro->u) (prolongateAndCorrectError, mg_3d.h:1331, folded
      * into the first launch's loads); the caller must have checked pro_fusable() */
     /* coarse != NULL (with want_res != 0): the residual is restricted on the fly into the interior of
@@ -511,7 +513,7 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
             {
                 StageScope kt(ctx, level, S == 4 ? MG3D_K_SWEEP4 : S == 2 ? (res ? MG3D_K_SWEEP2_RES : MG3D_K_SWEEP2)
                                                                           : MG3D_K_RESIDUAL, true);
-                np = k_sweep(l.g, l.f[MG3D_U], l.f[MG3D_D], l.alt,
+                np = k_sweep(l.g, (zero_in && passes == 2 * iters) ? nullptr : l.f[MG3D_U], l.f[MG3D_D], l.alt,
                              (res && want_res == 2 && !rst) ? l.f[MG3D_R] : nullptr, res ? ctx->partials : nullptr,
                              MG3D_MAX_PARTIALS, l.h, S, c1, res, s, 0, -1, rst ? &coarse->g : nullptr,
                              rst ? coarse->f[MG3D_D] : nullptr, -1, -1, with_pro ? &pro->g : nullptr,
@@ -654,13 +656,16 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
     const int L = ctx->L;
     for (int l = q; l >= 1; l--) {
         Level &lev = ctx->lv[l];
-        if (l < L - 1)
-            (void)hipMemsetAsync(lev.f[MG3D_U], 0, lev.elems * sizeof(double), s); /* :1258-1259 */
+        /* :1258-1259: the zero initial guess of a coarser level; with the fused sweep the first launch simply
+         * does not read u (and writes every plane of the other buffer), so no memset is needed */
+        const bool zero_in = l < L - 1 && ctx->fused && ctx->iters > 0;
+        if (l < L - 1 && !zero_in)
+            (void)hipMemsetAsync(lev.f[MG3D_U], 0, lev.elems * sizeof(double), s);
         if (ctx->fused) { /* pre-smoother and residual in one pass over the level (:1282 + :1294) */
             {
                 StageScope t(ctx, l, MG3D_ST_SMOOTH1);
                 enqueue_smooth_residual(ctx, l, 0, ctx->iters, 2, ctx->sumsq_slots - 1,
-                                        ctx->keep_r ? nullptr : &ctx->lv[l - 1]);
+                                        ctx->keep_r ? nullptr : &ctx->lv[l - 1], nullptr, zero_in);
             }
             StageScope t(ctx, l, MG3D_ST_RESIDUAL1); /* fused into the launch above: counted, ~0 s */
         } else {

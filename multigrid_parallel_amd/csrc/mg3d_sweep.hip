@@ -202,7 +202,9 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         for (int rr = 0; rr < RJ; rr++) {
             if (pl && row_in[rr] && pair_load) {
                 const long long p = g.plane * i + row_off[rr];
-                vv[rr] = *reinterpret_cast<const double2 *>(a.vin + p);
+                /* vin == NULL: the input field is identically zero (a coarse level's initial guess,
+                 * mg_3d.h:1258-1259) -- neither zeroed in memory beforehand nor read */
+                vv[rr] = a.vin ? *reinterpret_cast<const double2 *>(a.vin + p) : make_double2(0., 0.);
                 dd[rr] = *reinterpret_cast<const double2 *>(a.d + p);
             } else {
                 vv[rr] = make_double2(0., 0.);
