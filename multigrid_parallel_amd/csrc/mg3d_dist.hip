@@ -512,7 +512,8 @@ struct RestrictTarget { /* where a rank's restricted residual goes: coarse geome
  * interior planes [E, ni-E) -- those whose S-pass dependence cone (plus the pipeline's warm-up planes) does
  * not reach a halo plane: E = H + S + 3 -- and the two end windows follow once the halos have arrived.
  * All launches of the sweep read the same input and write disjoint planes of the alternate buffer. */
-static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const RestrictTarget *tgt, int xfield)
+static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const RestrictTarget *tgt, int xfield,
+                        bool zero_in = false /* u is identically zero: the first launch does not read it */)
 {
     hipStream_t s = D->stream;
     const int c1 = post ? 0 : 1;
@@ -548,7 +549,7 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
                 mg3d_ctx *cx = R.coarse;
                 const bool rst = res && tgt != nullptr && tgt[ri].dc != nullptr;
                 auto launch = [&](int i_lo, int i_hi) {
-                    return k_sweep(lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt,
+                    return k_sweep(lv.g, (zero_in && first) ? nullptr : lv.f[MG3D_U], lv.f[MG3D_D], lv.alt,
                                    (res && want_res == 2 && !rst) ? lv.f[MG3D_R] : nullptr, res ? cx->partials : nullptr,
                                    MG3D_MAX_PARTIALS, lv.h, S, c1, res, s, sl.own_lo, sl.own_hi,
                                    rst ? tgt[ri].gc : nullptr, rst ? tgt[ri].dc : nullptr, rst ? tgt[ri].lo : -1,
@@ -595,8 +596,7 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
         for (size_t ri = 0; ri < D->rs.size(); ri++) {
             RankState &R = D->rs[ri];
             SlabLevel &sl = SL(D, R, l);
-            if (l < L - 1)
-                (void)hipMemsetAsync(sl.lv.f[MG3D_U], 0, sl.lv.elems * sizeof(double), s); /* mg_3d.h:1258 */
+            /* mg_3d.h:1258: zero guess below the finest level -- folded into the first sweep launch */
             /* owned coarse planes (plus the physical boundary planes at the ends of the domain) */
             RestrictTarget &t = tgt[ri];
             if (l - 1 >= ld) {
@@ -618,7 +618,7 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
         /* :1282 + :1294 + :1310 (interior of the coarse rhs on the fly unless r is to be kept).  Halos to
          * refresh first: the finest u (left stale by the previous cycle's post-smoother) or, below, this
          * level's d (just restricted: only owned planes were produced). */
-        CHK(stage_smooth(D, l, 0, 2, keep ? none.data() : tgt.data(), l == L - 1 ? MG3D_U : MG3D_D));
+        CHK(stage_smooth(D, l, 0, 2, keep ? none.data() : tgt.data(), l == L - 1 ? MG3D_U : MG3D_D, l < L - 1));
         for (size_t ri = 0; ri < D->rs.size(); ri++) {
             SlabLevel &sl = SL(D, D->rs[ri], l);
             k_restrict(sl.lv.g, sl.lv.f[MG3D_R], *tgt[ri].gc, tgt[ri].dc, s, tgt[ri].lo, tgt[ri].hi, !keep);
