@@ -556,7 +556,16 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
                                    rst ? tgt[ri].hi : -1, nullptr, nullptr, i_lo, i_hi);
                 };
                 if (!split) {
-                    const int np = launch(-1, -1);
+                    /* a pure residual launch (S == 0) only has to produce what is consumed: the norm and the
+                     * on-the-fly restriction need the owned planes (their neighbours come from the pipeline's
+                     * warm-up / drain), a stored r one more plane on either side */
+                    int w_lo = -1, w_hi = -1;
+                    if (S == 0) {
+                        const int pad = (want_res == 2 && !rst) ? 1 : 0;
+                        w_lo = sl.own_lo - pad < 0 ? 0 : sl.own_lo - pad;
+                        w_hi = sl.own_hi + pad > lv.g.ni ? lv.g.ni : sl.own_hi + pad;
+                    }
+                    const int np = launch(w_lo, w_hi);
                     if (res)
                         k_fold(cx->partials, np, cx->sumsq, s);
                 } else if (phase == 0) {
