@@ -152,3 +152,16 @@ def test_api_surface_driver(tmp_path):
     assert lin == pytest.approx(list(norms), rel=1e-13)
     assert val("RES3")[0][0] == pytest.approx(norms[2], rel=1e-13)
     assert re.search(r"LEVEL 2\n.*\n\s+Smoother1\s+1\s", out)  # reset before the 4th cycle
+
+
+@pytest.mark.gpu
+def test_reference_test_mg_3d_129_cubed(tmp_path):
+    """BASELINE configs[1]: `9 5 2` = 129^3, V(2,2), through the unchanged reference driver."""
+    if not os.path.exists(BIN1):
+        pytest.skip("oracle/_ref/dropin_test_mg_3d was not built")
+    known = [600893, 73400.9, 9566.66, 1305, 183.942, 26.5851, 3.92421, 0.590481, 0.0904885, 0.014113, 0.00223841,
+             0.000360659, 5.89564e-05, 9.7633e-06, 1.63505e-06]
+    r = run([BIN1, "9", "5", "2"], tmp_path, 2)
+    assert r.returncode == 0, r.stderr
+    assert history(r.stdout) == pytest.approx(known, rel=2e-6)
+    assert float(re.search(r"Error norm:\s*(\S+)", r.stdout).group(1)) == pytest.approx(1.85423e-09, rel=1e-5)

@@ -470,3 +470,17 @@ def test_host_vcycle_started_below_the_finest_level():
     assert gn.value == pytest.approx(wn, rel=norm_rtol(Nq))
     for l in range(q + 1):
         assert np.array_equal(G_.u[l], H.u[l]) and np.array_equal(G_.d[l], H.d[l]) and np.array_equal(G_.r[l], H.r[l])
+
+
+def test_full_size_513_bit_exact_against_oracle():
+    """BASELINE's headline size, two V(2,2) cycles: the whole 513^3 solution vector (1.08 GB) is bit-identical to the
+    oracle's (OpenMP over the host cores; the oracle's grid values do not depend on the thread count)."""
+    O.lib().orc_set_threads(min(16, os.cpu_count() or 1))
+    want_norms, want_u, _, _ = O.run_problem(9, 7, 2, 2)
+    with M.Solver(9, 7, 2) as s:
+        s.setup_test_problem()
+        got = s.vcycles(2)
+        u = s.download(MG3D_U, 6)
+    assert np.array_equal(u, want_u)
+    np.testing.assert_allclose(got, want_norms, rtol=norm_rtol(513))
+    O.lib().orc_set_threads(1)
