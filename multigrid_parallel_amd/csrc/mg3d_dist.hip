@@ -555,11 +555,21 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
                                    rst ? tgt[ri].gc : nullptr, rst ? tgt[ri].dc : nullptr, rst ? tgt[ri].lo : -1,
                                    rst ? tgt[ri].hi : -1, nullptr, nullptr, i_lo, i_hi);
                 };
+                /* output planes of a smoothing launch: the owned planes plus what the next consumer reads beyond
+                 * them -- the residual/restriction behind a pre-smoother needs u on owned +-2, the prolongation
+                 * to the next finer level and the top-level norm need owned +-1; the remaining halo planes are
+                 * refreshed by an exchange before anything reads them again */
+                const int margin = post ? 1 : 2;
+                /* only the LAST smoothing launch of the stage may be trimmed: an earlier one feeds the next
+                 * launch's whole dependence cone */
+                const bool trim = last;
+                const int o_lo = (!trim || sl.own_lo - margin < 0) ? 0 : sl.own_lo - margin;
+                const int o_hi = (!trim || sl.own_hi + margin > lv.g.ni) ? lv.g.ni : sl.own_hi + margin;
                 if (!split) {
                     /* a pure residual launch (S == 0) only has to produce what is consumed: the norm and the
                      * on-the-fly restriction need the owned planes (their neighbours come from the pipeline's
                      * warm-up / drain), a stored r one more plane on either side */
-                    int w_lo = -1, w_hi = -1;
+                    int w_lo = o_lo, w_hi = o_hi;
                     if (S == 0) {
                         const int pad = (want_res == 2 && !rst) ? 1 : 0;
                         w_lo = sl.own_lo - pad < 0 ? 0 : sl.own_lo - pad;
@@ -571,8 +581,8 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
                 } else if (phase == 0) {
                     launch(E, lv.g.ni - E);
                 } else {
-                    launch(0, E);
-                    launch(lv.g.ni - E, lv.g.ni);
+                    launch(o_lo, E);
+                    launch(lv.g.ni - E, o_hi);
                 }
             }
         }
