@@ -518,25 +518,39 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
     const Geom &g = a.g;
     a.ntj = (g.nj + VJ - 1) / VJ;
     a.ntk = (g.nk + VK - 1) / VK;
-    /* i-chunk length: every chunk pays ST warm-up planes, but a level needs a few hundred blocks to keep
-     * 256 CUs busy and short chunks mean fewer dependent steps.  Measured optimum on MI355X: about
-     * 500-1000 blocks (513^3: CI 64-128, 257^3: 16, 129^3: 8, <= 65^3: 2-4). */
+    /* i-chunk length: every chunk pays `ovh` extra steps (warm-up planes, pipeline drain), but a level needs
+     * a few hundred blocks to keep 256 CUs busy (one 512-thread block per CU) and short chunks mean fewer
+     * dependent steps.  Measured optimum on MI355X: about 500-1000 blocks for a full level (513^3: CI 64-128,
+     * 257^3: 16, 129^3: 8, <= 65^3: 2-4; pure residual launches tolerate shorter chunks). */
     const int nout = a.i_hi - a.i_lo;
     auto blocks = [&](int ci) { return (long long)a.ntj * a.ntk * ((nout + ci - 1) / ci); };
+    const int ovh = Sh::HI + Sh::ST + (RES == 2 ? 2 : 0) + 1;
     int CI = RES == 2 ? 16 : 8; /* the fused restriction pays two more warm-up planes and two drain steps */
-    const long long most = RES == 2 ? 1000 : Sh::ST <= 2 ? 1600 : 800; /* a short pipeline tolerates shorter chunks */
+    const long long most = RES == 2 ? 1000 : Sh::ST <= 2 ? 1600 : 800;
     while (CI < 128 && blocks(CI) > most)
         CI *= 2;
     while (CI > 2 && blocks(CI) < 100)
         CI /= 2;
+    /* a thin plane range (an i-slab of a multi-GPU run): if some exact division fits in ONE round of blocks
+     * and clearly beats the multi-round choice above, take it (68 planes of 513^2: 2 chunks of 34) */
+    if (blocks(CI) > 256) {
+        const double cur = (double)blocks(CI) / 256.0 * (CI + ovh);
+        for (int k = 1; k <= 8; k++) {
+            const int ci = (nout + k - 1) / k;
+            if (ci >= 2 && blocks(ci) <= 256 && (double)(ci + ovh) < 0.9 * cur) {
+                CI = ci;
+                break; /* smallest k = fewest, longest chunks that already fit... keep the first that fits */
+            }
+        }
+    }
     if (const char *e = getenv("MG3D_SWEEP_CI"))
         CI = atoi(e) > 0 ? atoi(e) : CI;
     while (a.partials && blocks(CI) + 8 > max_partials && CI < nout)
         CI *= 2; /* one partial sum per block must fit the caller's buffer */
     if (CI > nout)
         CI = nout;
-    if (RES == 2 && (CI & 1))
-        CI += 1; /* chunk starts keep their parity relative to i_lo */
+    if (CI < 1)
+        CI = 1;
     a.CI = CI;
     a.nci = (nout + CI - 1) / CI;
     /* measured on MI355X (513^3, S=4): the remap cuts L2 misses by 20 % but runs 5-10 % slower; off by default */
