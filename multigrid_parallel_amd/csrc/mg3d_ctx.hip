@@ -485,8 +485,11 @@ static int read_norm(mg3d_ctx *ctx, int slot, double *norm)
  * alternate buffer; the residual rides on the last launch.  want_res: 0 none, 1 norm only,
  * 2 store r (+ norm).  The squared norm goes to sumsq[slot]. */
 static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters, int want_res, int slot,
-                                    Level *coarse = nullptr, const Level *pro = nullptr, bool zero_in = false)
+                                    Level *coarse = nullptr, const Level *pro = nullptr, bool zero_in = false,
+                                    bool need_norm = true)
 {
+    /* need_norm = false: only r (or its restriction) is wanted -- the V-cycle drops the pre-smoothing norm
+     * (mg_3d.h:1294 ignores calculateResidual's value) -- so no partial sums are produced or folded */
     /* zero_in: u of this level is to be taken as identically zero (the memset of mg_3d.h:1258-1259 folded
      * into the first launch: it neither reads u nor needs it zeroed); only valid when a launch with S > 0 follows */
     /* pro != NULL: the smoother's input is u + P(pro->u) (prolongateAndCorrectError, mg_3d.h:1331, folded
@@ -514,7 +517,8 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
                 StageScope kt(ctx, level, S == 4 ? MG3D_K_SWEEP4 : S == 2 ? (res ? MG3D_K_SWEEP2_RES : MG3D_K_SWEEP2)
                                                                           : MG3D_K_RESIDUAL, true);
                 np = k_sweep(l.g, (zero_in && passes == 2 * iters) ? nullptr : l.f[MG3D_U], l.f[MG3D_D], l.alt,
-                             (res && want_res == 2 && !rst) ? l.f[MG3D_R] : nullptr, res ? ctx->partials : nullptr,
+                             (res && want_res == 2 && !rst) ? l.f[MG3D_R] : nullptr,
+                             (res && need_norm) ? ctx->partials : nullptr,
                              MG3D_MAX_PARTIALS, l.h, S, c1, res, s, 0, -1, rst ? &coarse->g : nullptr,
                              rst ? coarse->f[MG3D_D] : nullptr, -1, -1, with_pro ? &pro->g : nullptr,
                              with_pro ? pro->f[MG3D_U] : nullptr);
@@ -525,7 +529,8 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
                 l.alt = t;
             }
             if (res) {
-                k_fold(ctx->partials, np, ctx->sumsq + slot, s);
+                if (need_norm)
+                    k_fold(ctx->partials, np, ctx->sumsq + slot, s);
                 done_res = true;
             }
             passes -= S;
@@ -665,7 +670,7 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
             {
                 StageScope t(ctx, l, MG3D_ST_SMOOTH1);
                 enqueue_smooth_residual(ctx, l, 0, ctx->iters, 2, ctx->sumsq_slots - 1,
-                                        ctx->keep_r ? nullptr : &ctx->lv[l - 1], nullptr, zero_in);
+                                        ctx->keep_r ? nullptr : &ctx->lv[l - 1], nullptr, zero_in, false);
             }
             StageScope t(ctx, l, MG3D_ST_RESIDUAL1); /* fused into the launch above: counted, ~0 s */
         } else {

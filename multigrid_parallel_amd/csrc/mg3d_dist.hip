@@ -550,7 +550,8 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
                 const bool rst = res && tgt != nullptr && tgt[ri].dc != nullptr;
                 auto launch = [&](int i_lo, int i_hi) {
                     return k_sweep(lv.g, (zero_in && first) ? nullptr : lv.f[MG3D_U], lv.f[MG3D_D], lv.alt,
-                                   (res && want_res == 2 && !rst) ? lv.f[MG3D_R] : nullptr, res ? cx->partials : nullptr,
+                                   (res && want_res == 2 && !rst) ? lv.f[MG3D_R] : nullptr,
+                                   (res && want_res == 1) ? cx->partials : nullptr, /* the pre-smoothing norm is dropped (:1294) */
                                    MG3D_MAX_PARTIALS, lv.h, S, c1, res, s, sl.own_lo, sl.own_hi,
                                    rst ? tgt[ri].gc : nullptr, rst ? tgt[ri].dc : nullptr, rst ? tgt[ri].lo : -1,
                                    rst ? tgt[ri].hi : -1, nullptr, nullptr, i_lo, i_hi);
@@ -576,7 +577,7 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
                         w_hi = sl.own_hi + pad > lv.g.ni ? lv.g.ni : sl.own_hi + pad;
                     }
                     const int np = launch(w_lo, w_hi);
-                    if (res)
+                    if (res && want_res == 1)
                         k_fold(cx->partials, np, cx->sumsq, s);
                 } else if (phase == 0) {
                     launch(E, lv.g.ni - E);
