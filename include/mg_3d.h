@@ -120,15 +120,27 @@ static inline void updateEdgeValues(double *v, const int N) { mg3d_smooth_edges_
 /* GetL2NormOfVector, mg_3d.h:783-792 */
 static inline double GetL2NormOfVector(const double *v, const int n) { return mg3d_l2norm_host(v, n); }
 
-/* ---- grid operators on host arrays (mg_3d.h:640-1145), executed on the GPU ----------- */
+/* ---- grid operators on host arrays (mg_3d.h:640-1145), executed on the GPU -----------
+ * In the reference these are orphaned `omp for` constructs: inside a parallel region every
+ * thread of the team calls them together (mg_3d.h:1282-1341, test_rb_gs_3d.c:70-71) and the
+ * implicit barrier of the last loop ends the call.  Here the master thread runs the GPU work
+ * between two team barriers; a serial call (test_mg_3d_dirichlet.c) has a team of one. */
+#define MG3D_TEAM_CALL_(expr, what) \
+    do {                            \
+        _Pragma("omp barrier")      \
+        _Pragma("omp master")       \
+        mg3d_die_((expr), (what));  \
+        _Pragma("omp barrier")      \
+    } while (0)
+
 static inline void preSmoother(double *v, const double *rhs, const int N, const double h, const int smootherIter)
 {
-    mg3d_die_(mg3d_host_smooth(v, rhs, N, h, smootherIter, 0), "preSmoother");
+    MG3D_TEAM_CALL_(mg3d_host_smooth(v, rhs, N, h, smootherIter, 0), "preSmoother");
 }
 
 static inline void postSmoother(double *v, const double *rhs, const int N, const double h, const int smootherIter)
 {
-    mg3d_die_(mg3d_host_smooth(v, rhs, N, h, smootherIter, 1), "postSmoother");
+    MG3D_TEAM_CALL_(mg3d_host_smooth(v, rhs, N, h, smootherIter, 1), "postSmoother");
 }
 
 /* Called by every thread of an OpenMP team in the reference (orphaned `omp for`,
@@ -147,12 +159,12 @@ static inline double calculateResidual(const double *v, const double *rhs, const
 
 static inline void restrictResidual(const double *res, const int Nf, double *dc, const int Nc)
 {
-    mg3d_die_(mg3d_host_restrict(res, Nf, dc, Nc), "restrictResidual");
+    MG3D_TEAM_CALL_(mg3d_host_restrict(res, Nf, dc, Nc), "restrictResidual");
 }
 
 static inline void prolongateAndCorrectError(const double *ec, const int Nc, double *ef, const int Nf)
 {
-    mg3d_die_(mg3d_host_prolong(ec, Nc, ef, Nf), "prolongateAndCorrectError");
+    MG3D_TEAM_CALL_(mg3d_host_prolong(ec, Nc, ef, Nf), "prolongateAndCorrectError");
 }
 
 /* vcycle on caller-owned host hierarchies, mg_3d.h:1242-1362.  Team-safe like
@@ -175,9 +187,9 @@ static inline double mg3d_vcycle9_(double **lu_, double **lf_, double **lres_, d
                   "vcycle");
         if (timed)
             for (int l = 0; l <= q; l++)
-                for (int s = 0; s < MG3D_NUM_STAGES && s < tInfo[l]->numStages; s++) {
-                    tInfo[l]->numCalls[s] += calls[l * MG3D_NUM_STAGES + s];
-                    tInfo[l]->timeTaken[s] += secs[l * MG3D_NUM_STAGES + s];
+                for (int s = 0; s < MG3D_NUM_STAGES && s < MG3D_TI_NSTAGES_(tInfo, l); s++) {
+                    MG3D_TI_CALLS_(tInfo, l, s) += calls[l * MG3D_NUM_STAGES + s];
+                    MG3D_TI_TIME_(tInfo, l, s) += secs[l * MG3D_NUM_STAGES + s];
                 }
     }
 #pragma omp barrier
@@ -326,16 +338,16 @@ static inline void SolverPrintTimingInfo(void)
     mg3d_pull_(); /* the sync point between the solve loop and the caller's reads of `grid` */
     for (int l = 0; l < numLevels; l++) {
         for (int s = 0; s < MG3D_NUM_STAGES; s++)
-            mg3d_die_(mg3d_timing_get(mg3d_solver_ctx_, l, s, &tInfo[l]->numCalls[s], &tInfo[l]->timeTaken[s]),
+            mg3d_die_(mg3d_timing_get(mg3d_solver_ctx_, l, s, &MG3D_TI_CALLS_(tInfo, l, s), &MG3D_TI_TIME_(tInfo, l, s)),
                       "SolverPrintTimingInfo");
         /* as the reference: "Recurse, Direct Solve" of level l is the time spent below l (mg_3d.h:1318-1325) */
     }
     for (int l = 1; l < numLevels; l++) {
         double below = 0.;
         for (int s = 0; s < MG3D_NUM_STAGES; s++)
-            below += tInfo[l - 1]->timeTaken[s];
-        tInfo[l]->timeTaken[MG3D_ST_RECURSE] = below;
-        tInfo[l]->numCalls[MG3D_ST_RECURSE] = tInfo[l]->numCalls[MG3D_ST_SMOOTH1];
+            below += MG3D_TI_TIME_(tInfo, l - 1, s);
+        MG3D_TI_TIME_(tInfo, l, MG3D_ST_RECURSE) = below;
+        MG3D_TI_CALLS_(tInfo, l, MG3D_ST_RECURSE) = MG3D_TI_CALLS_(tInfo, l, MG3D_ST_SMOOTH1);
     }
     printTimingInfo(tInfo, numLevels);
 }

@@ -17,6 +17,8 @@ ROOT = O.ROOT
 REF = "/root/reference"
 BIN1 = os.path.join(ROOT, "oracle", "_ref", "dropin_test_mg_3d")
 BIN2 = os.path.join(ROOT, "oracle", "_ref", "dropin_test_mg_3d_dirichlet")
+BIN3 = os.path.join(ROOT, "oracle", "_ref", "dropin_test_rb_gs_3d")  # built with -DMG3D_LEGACY_TIMINGINFO
+BIN4 = os.path.join(ROOT, "oracle", "_ref", "dropin_test_lu")
 HAVE_GPU = os.path.exists("/dev/kfd")
 
 
@@ -30,7 +32,7 @@ def run(cmd, cwd, threads=None):
 @pytest.mark.skipif(not os.path.exists(REF), reason="reference tree only exists in the build container")
 def test_reference_drivers_compile_and_link_unchanged(tmp_path):
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "dropin"], check=True, capture_output=True)
-    assert os.path.exists(BIN1) and os.path.exists(BIN2)
+    assert all(os.path.exists(b) for b in (BIN1, BIN2, BIN3, BIN4))
     out = subprocess.run(["ldd", BIN1], capture_output=True, text=True).stdout
     assert "libmg3d.so" in out and "multigrid_parallel_amd/lib" in out
     # argument handling is the reference's: usage + exit 1 (mg_3d.h:109-113), abort on non-pow2 (:123)
@@ -38,14 +40,23 @@ def test_reference_drivers_compile_and_link_unchanged(tmp_path):
     assert r.returncode == 1 and r.stdout.startswith("Usage:")
     r = run([BIN1, "4", "3", "2"], tmp_path)
     assert r.returncode == -6 or r.returncode == 134
-    r = run([BIN2], tmp_path)
-    assert r.returncode == 1 and r.stdout.startswith("Usage:")
+    for b in (BIN2, BIN3, BIN4):
+        r = run([b], tmp_path)
+        assert r.returncode == 1 and r.stdout.startswith("Usage:")
+    # the legacy TimingInfo generation also serves the dirichlet driver (its tInfo[level][stage] shape)
+    with open(os.path.join(REF, "test_mg_3d_dirichlet.c")) as src:
+        subprocess.run(["gcc", "-x", "c", "-fopenmp", "-w", "-DMG3D_LEGACY_TIMINGINFO", "-fsyntax-only",
+                        "-I" + os.path.join(ROOT, "include"), "-"], stdin=src, check=True, cwd=tmp_path)
 
 
 @pytest.mark.skipif(HAVE_GPU or not os.path.exists(BIN1), reason="needs the CPU-only container")
 def test_drivers_fail_loudly_without_gpu(tmp_path):
     for b in (BIN1, BIN2):
         r = run([b, "5", "3", "2"], tmp_path)
+        assert r.returncode == 1
+        assert "no CPU fallback" in r.stderr
+    for b in (BIN3, BIN4):
+        r = run([b, "5"], tmp_path)
         assert r.returncode == 1
         assert "no CPU fallback" in r.stderr
 
@@ -165,3 +176,72 @@ def test_reference_test_mg_3d_129_cubed(tmp_path):
     assert r.returncode == 0, r.stderr
     assert history(r.stdout) == pytest.approx(known, rel=2e-6)
     assert float(re.search(r"Error norm:\s*(\S+)", r.stdout).group(1)) == pytest.approx(1.85423e-09, rel=1e-5)
+
+
+def rb_gs_history(N, tol=1e-6):
+    """test_rb_gs_3d.c:56-101 replayed with the oracle: one pre + one post sweep and the norm per iteration."""
+    lib = O.lib()
+    h = 1.0 / (N - 1)
+    u, d = np.zeros(N ** 3), np.zeros(N ** 3)
+    lib.orc_fill_boundary(O.P(u), N, h)
+    init = lib.orc_residual(O.P(u), O.P(d), N, h, None)
+    out, nrm = [], 1e9
+    while nrm > init * tol:
+        lib.orc_pre_smooth(O.P(u), O.P(d), N, h, 1)
+        lib.orc_post_smooth(O.P(u), O.P(d), N, h, 1)
+        old, nrm = nrm, lib.orc_residual(O.P(u), O.P(d), N, h, None)
+        out.append((nrm, nrm / old))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,threads", [(18, 1), (18, 4), (33, 3)])
+def test_reference_test_rb_gs_3d_runs_on_gpu(tmp_path, N, threads):
+    """The smoother-only driver, unchanged: every thread of the team calls preSmoother /
+    postSmoother / calculateResidual (test_rb_gs_3d.c:70-80), N is not of the form 2^k+1."""
+    if not os.path.exists(BIN3):
+        pytest.skip("oracle/_ref/dropin_test_rb_gs_3d was not built")
+    r = run([BIN3, str(N)], tmp_path, threads)
+    assert r.returncode == 0, r.stderr
+    want = rb_gs_history(N)
+    got = re.findall(r"^\s*(\d+)\s+Residual Norm:\s*(\S+)\s+ResidRatio:\s*(\S+)", r.stdout, flags=re.M)
+    assert [int(g[0]) for g in got] == list(range(1, len(want) + 1))
+    assert [float(g[1]) for g in got] == pytest.approx([w[0] for w in want], rel=6e-6)  # %20g: 6 significant digits
+    assert [float(g[2]) for g in got[1:]] == pytest.approx([w[1] for w in want[1:]], rel=6e-6)
+    assert f"Max OMP threads: {threads}" in r.stdout
+    assert f"Number of calls: {len(want)}" in r.stdout
+
+
+@pytest.mark.gpu
+def test_reference_test_rb_gs_3d_50_cubed(tmp_path):
+    """The size of the reference's only published numbers (red_black_gs_scalability.txt): 50^3, tol 1e-6.
+    The unmodified operators of the current tree need 1303 iterations (0.28129 / 0.991804), see DESIGN.md."""
+    if not os.path.exists(BIN3):
+        pytest.skip("oracle/_ref/dropin_test_rb_gs_3d was not built")
+    r = run([BIN3, "50"], tmp_path, 2)
+    assert r.returncode == 0, r.stderr
+    last = re.findall(r"^\s*(\d+)\s+Residual Norm:\s*(\S+)\s+ResidRatio:\s*(\S+)", r.stdout, flags=re.M)[-1]
+    assert (int(last[0]), last[1], last[2]) == (1303, "0.28129", "0.991804")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [3, 5, 9])
+def test_reference_test_lu_runs_on_gpu(tmp_path, N):
+    """test_lu.c unchanged: constructCoarseMatrixA + convertToLU_InPlace on the host, solveWithLU on the GPU,
+    result written as VTK (9 significant digits)."""
+    if not os.path.exists(BIN4):
+        pytest.skip("oracle/_ref/dropin_test_lu was not built")
+    r = run([BIN4, str(N)], tmp_path, 1)
+    assert r.returncode == 0, r.stderr
+    assert "Time taken for LU solve:" in r.stdout
+    lib = O.lib()
+    n, h = N ** 3, 1.0 / (N - 1)
+    A, b, x = np.zeros(n * n), np.zeros(n), np.zeros(n)
+    lib.orc_coarse_matrix(O.P(A), N, h)
+    lib.orc_lu_factor(O.P(A), n)
+    lib.orc_fill_boundary(O.P(b), N, h)
+    lib.orc_lu_solve(O.P(A), n, O.P(b), O.P(x))
+    text = (tmp_path / "output.vtk").read_text()
+    body = text[text.index("LOOKUP_TABLE"):].split("\n", 1)[1].split()
+    got = np.array([float(t) for t in body[:n]])
+    assert np.allclose(got, x, rtol=2e-8, atol=1e-300)  # "%10.8e", values in memory order (postprocess.h:37-44)
