@@ -143,6 +143,8 @@ static void free_lu(mg3d_ctx *ctx)
         (void)hipFree(ctx->lu.lrot);
     if (ctx->lu.urot)
         (void)hipFree(ctx->lu.urot);
+    if (ctx->lu.stream)
+        (void)hipFree(ctx->lu.stream);
     if (ctx->lu_work)
         (void)hipFree(ctx->lu_work);
     memset(&ctx->lu, 0, sizeof ctx->lu);
@@ -318,9 +320,16 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
         if (hi - i > bw)
             bw = (int)(hi - i);
     }
-    std::vector<double> lcol((size_t)n * bw, 0.), ucol((size_t)n * bw, 0.), diag((size_t)n);
+    std::vector<double> lcol((size_t)n * bw, 0.), ucol((size_t)n * bw, 0.), diag((size_t)2 * ((n + 63) / 64 * 64), 1.);
+    int fast_div = 1;
+    const long long npad = (n + 63) / 64 * 64;
     for (long long j = 0; j < n; j++) {
         diag[j] = LU[j * n + j];
+        /* reciprocal for lu_div(): correctly rounded by the host's IEEE division; 0 = "divide the ordinary way" */
+        const double ad = fabs(diag[j]);
+        if (!(ad >= 0x1p-460 && ad <= 0x1p460))
+            fast_div = 0;
+        diag[npad + j] = 1.0 / diag[j];
         for (int t = 0; t < bw; t++) {
             const long long il = j + 1 + t, iu = j - 1 - t;
             if (il < n)
@@ -332,6 +341,8 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
     free_lu(ctx);
     ctx->lu.n = (int)n;
     ctx->lu.bw = bw;
+    ctx->lu.fast_div = fast_div;
+    ctx->lu.npad = (int)npad;
     HIPCHK(hipMalloc(&ctx->lu.lcol, lcol.size() * sizeof(double)));
     HIPCHK(hipMalloc(&ctx->lu.ucol, ucol.size() * sizeof(double)));
     HIPCHK(hipMalloc(&ctx->lu.diag, diag.size() * sizeof(double)));
@@ -341,7 +352,7 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
     HIPCHK(hipMemcpy(ctx->lu.diag, diag.data(), diag.size() * sizeof(double), hipMemcpyHostToDevice));
     /* narrow bands (coarse grids up to 11^3): lane-rotated copies for the single-wave kernel */
     const int R = (bw + 63) / 64;
-    if (R <= 2 && 3 * (size_t)n * sizeof(double) <= 60000) {
+    if (R <= 2 && 4 * (size_t)n * sizeof(double) <= 60000) {
         std::vector<double> lrot((size_t)n * 64 * R, 0.), urot((size_t)n * 64 * R, 0.);
         for (long long j = 0; j < n; j++)
             for (int q = 0; q < R; q++)
@@ -358,6 +369,28 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
         HIPCHK(hipMemcpy(ctx->lu.lrot, lrot.data(), lrot.size() * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(ctx->lu.urot, urot.data(), urot.size() * sizeof(double), hipMemcpyHostToDevice));
         ctx->lu.rot_r = R;
+        /* stream for the loader/solver kernel (see lu_solve_stream_kernel) when its LDS ring fits */
+        const int CH = mg3d_lu_stream_chunk((int)n, R);
+        if (CH > 0) {
+            const long long nch = npad / CH, step_d = 64 * R;
+            std::vector<double> st((size_t)((2 * nch + 2) * CH * step_d), 0.);
+            /* per lane the pair is stored as (factor for sum A, factor for sum B) of lu_stream_half: a lane
+             * that has already finalised its unknown of the current 64-step chunk (or does so in this step)
+             * carries its nearer row in B */
+            for (long long j = 0; j < n; j++)
+                for (int l = 0; l < 64; l++) {
+                    const int of = (int)(j & 63), ob = (int)(j & 63);
+                    const bool swf = R == 2 && l <= of, swb = R == 2 && l >= ob;
+                    for (int q = 0; q < R; q++) {
+                        const int qf = swf ? 1 - q : q, qb = swb ? 1 - q : q;
+                        st[(size_t)(j * step_d + l * R + qf)] = lrot[(size_t)j * 64 * R + 64 * q + l];
+                        st[(size_t)((npad + (npad - 1 - j)) * step_d + l * R + qb)] = urot[(size_t)j * 64 * R + 64 * q + l];
+                    }
+                }
+            HIPCHK(hipMalloc(&ctx->lu.stream, st.size() * sizeof(double)));
+            HIPCHK(hipMemcpy(ctx->lu.stream, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice));
+            ctx->lu.stream_ch = CH;
+        }
     }
     return MG3D_OK;
 }

@@ -12,10 +12,21 @@
  * Halo: H = 2*nu + 2 planes on each side.  The fused sweep applies S = 2*nu colour passes per launch; a
  * slab end that is not refreshed between passes goes stale one plane per pass, so after a sweep the
  * local planes [S, ni-S) are exact, the residual on [S+1, ni-S-1) -- which covers the owned planes and
- * the one extra fine plane restriction needs (H = S+2).  Exchanges per distributed level and cycle:
- * d of the next coarser level after restriction, u after prolongation (before post-smoothing); at the
- * finest level also u after post-smoothing (the next cycle starts from it).  Planes are contiguous in
- * memory, so a halo is one ncclSend/ncclRecv pair per neighbour, no packing.
+ * the one extra fine plane restriction needs (H = S+2).  Planes are contiguous in memory, so a halo is
+ * one ncclSend/ncclRecv pair per neighbour, no packing.
+ *
+ * Exchanges per distributed level l and cycle:
+ *   d_(l-1)  after restriction (small; on the compute stream, the coarser level needs it at once);
+ *   u_l      after pre-smoothing + restriction.  Nothing touches u_l again until the prolongation on the
+ *            way up, so this -- the large one -- runs on the communication stream (its own communicator)
+ *            underneath all the smoothing of the coarser levels;
+ *   u_(l-1)  after the coarser level's post-smoothing (an eighth of the volume): with fresh halos on the
+ *            coarse correction AND on u_l the prolongation is applied to halo planes as well, and the
+ *            post-smoother starts at once from 6 exact halo planes, one launch, no exchange;
+ *   finest u after post-smoothing, for the next cycle's pre-smoother: on the communication stream,
+ *            underneath the residual-norm kernel.  That kernel reads the first halo plane on either side,
+ *            so the exchange leaves it alone (the local post-smoother already produced its exact value)
+ *            and refreshes planes 2..H only.
  *
  * Transports: RCCL (ncclCommInitRank from a unique id the launcher distributes), or "loopback": all
  * ranks are virtual, live in this process on one GPU and exchange by device copies -- the same
@@ -110,11 +121,14 @@ struct mg3d_dist {
     double length;
     bool loopback;
     int device;
-    ncclComm_t comm;
-    bool have_comm;
+    ncclComm_t comm;  /* compute-stream collectives and exchanges */
+    ncclComm_t comm2; /* communication-stream exchanges (ncclCommSplit of comm: may run concurrently with it) */
+    bool have_comm, have_comm2;
     hipStream_t stream; /* every operation of every local rank is ordered on this one stream */
-    hipStream_t comm_stream; /* halo exchanges that overlap interior smoothing run here */
-    hipEvent_t ev_ready, ev_done;
+    hipStream_t comm_stream; /* the u halo exchanges that hide under coarser levels / the norm run here */
+    hipEvent_t ev_ready;
+    std::vector<hipEvent_t> ev_u; /* per level: "the u halos of this level have arrived" */
+    std::vector<char> u_pending;  /* per level: ev_u[l] has been recorded and not yet waited for */
     bool overlap; /* MG3D_NO_OVERLAP=1 keeps every exchange on the compute stream */
     std::vector<RankState> rs;
     double *h_norms; /* pinned */
@@ -156,8 +170,9 @@ extern "C" int mg3d_dist_destroy(mg3d_dist *D)
         (void)hipStreamSynchronize(D->stream);
     if (D->ev_ready)
         (void)hipEventDestroy(D->ev_ready);
-    if (D->ev_done)
-        (void)hipEventDestroy(D->ev_done);
+    for (auto e : D->ev_u)
+        if (e)
+            (void)hipEventDestroy(e);
     if (D->comm_stream)
         (void)hipStreamDestroy(D->comm_stream);
     for (auto &R : D->rs) {
@@ -184,6 +199,8 @@ extern "C" int mg3d_dist_destroy(mg3d_dist *D)
         (void)hipFree(D->d_norms);
     if (D->h_norms)
         (void)hipHostFree(D->h_norms);
+    if (D->have_comm2)
+        (void)ncclCommDestroy(D->comm2);
     if (D->have_comm)
         (void)ncclCommDestroy(D->comm);
     delete D;
@@ -208,11 +225,11 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
     D->ld = mg3d_slab_first_level(coarse_pts, num_levels, nranks, D->H);
     D->loopback = unique_id == nullptr;
     D->device = device;
-    D->have_comm = false;
+    D->have_comm = D->have_comm2 = false;
     D->stream = nullptr;
     D->h_norms = D->d_norms = nullptr;
     D->comm_stream = nullptr;
-    D->ev_ready = D->ev_done = nullptr;
+    D->ev_ready = nullptr;
     D->overlap = !(getenv("MG3D_NO_OVERLAP") && getenv("MG3D_NO_OVERLAP")[0] == '1');
     if (D->ld >= num_levels) {
         delete D;
@@ -290,7 +307,10 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
     }
     DCHK(hipStreamCreateWithFlags(&D->comm_stream, hipStreamNonBlocking));
     DCHK(hipEventCreateWithFlags(&D->ev_ready, hipEventDisableTiming));
-    DCHK(hipEventCreateWithFlags(&D->ev_done, hipEventDisableTiming));
+    D->ev_u.assign(num_levels, nullptr);
+    D->u_pending.assign(num_levels, 0);
+    for (int l = D->ld; l < num_levels; l++)
+        DCHK(hipEventCreateWithFlags(&D->ev_u[l], hipEventDisableTiming));
     D->norm_slots = 1024;
     DCHK(hipMalloc(&D->d_norms, sizeof(double) * D->norm_slots));
     DCHK(hipHostMalloc(&D->h_norms, sizeof(double) * D->norm_slots));
@@ -306,6 +326,18 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
             return rc;
         }
         D->have_comm = true;
+        /* a second communicator for the communication stream: two RCCL operations may only be in flight
+         * together on different communicators.  Without it the exchanges stay on the compute stream. */
+        if (D->overlap) {
+            e = ncclCommSplit(D->comm, 0, rank, &D->comm2, nullptr);
+            if (e == ncclSuccess)
+                D->have_comm2 = true;
+            else {
+                fprintf(stderr, "libmg3d: ncclCommSplit failed (%s): halo exchanges will not be overlapped\n",
+                        ncclGetErrorString(e));
+                D->overlap = false;
+            }
+        }
     }
     *out = D;
     return MG3D_OK;
@@ -398,19 +430,22 @@ extern "C" int mg3d_dist_sync(mg3d_dist *D)
 }
 
 /* --------------------------------------------------------------------------------------- transport */
-/* refresh the H halo planes of `field` on distributed level l from the neighbours' owned planes */
-static int exchange_halo(mg3d_dist *D, int field, int l, hipStream_t s)
+/* Refresh the halo planes skip+1 .. H (counted from the slab's owned planes) of `field` on distributed level
+ * l from the neighbours' owned planes; skip = 0 is the whole halo.  Halo plane t of the upper side is the
+ * neighbour's owned plane t (t = 1: its first), of the lower side the lower neighbour's t-th from the top. */
+static int exchange_halo(mg3d_dist *D, int field, int l, hipStream_t s, int skip = 0)
 {
-    const int H = D->H;
-    if (D->P == 1)
+    const int H = D->H, n = D->H - skip;
+    if (D->P == 1 || n <= 0)
         return MG3D_OK;
     if (D->loopback) {
         for (int r = 0; r + 1 < D->P; r++) {
             SlabLevel &a = SL(D, D->rs[r], l), &b = SL(D, D->rs[r + 1], l);
-            const size_t bytes = (size_t)H * a.lv.g.plane * sizeof(double);
-            /* r's upper halo <- first H owned planes of r+1 ; (r+1)'s lower halo <- last H owned planes of r */
-            HIPCHK(hipMemcpyAsync(a.lv.f[field] + a.lv.g.plane * a.own_hi, b.lv.f[field] + b.lv.g.plane * b.own_lo,
-                                  bytes, hipMemcpyDeviceToDevice, s));
+            const size_t bytes = (size_t)n * a.lv.g.plane * sizeof(double);
+            /* r's upper halo <- first owned planes of r+1 ; (r+1)'s lower halo <- last owned planes of r */
+            HIPCHK(hipMemcpyAsync(a.lv.f[field] + a.lv.g.plane * (a.own_hi + skip),
+                                  b.lv.f[field] + b.lv.g.plane * (b.own_lo + skip), bytes, hipMemcpyDeviceToDevice,
+                                  s));
             HIPCHK(hipMemcpyAsync(b.lv.f[field] + b.lv.g.plane * (b.own_lo - H),
                                   a.lv.f[field] + a.lv.g.plane * (a.own_hi - H), bytes, hipMemcpyDeviceToDevice, s));
         }
@@ -418,18 +453,44 @@ static int exchange_halo(mg3d_dist *D, int field, int l, hipStream_t s)
     }
     RankState &R = D->rs[0];
     SlabLevel &a = SL(D, R, l);
-    const size_t cnt = (size_t)H * a.lv.g.plane;
+    const size_t cnt = (size_t)n * a.lv.g.plane;
     double *f = a.lv.f[field];
+    ncclComm_t comm = (s == D->comm_stream && D->have_comm2) ? D->comm2 : D->comm;
     NCCLCHK(ncclGroupStart());
     if (R.rank + 1 < D->P) {
-        NCCLCHK(ncclSend(f + a.lv.g.plane * (a.own_hi - H), cnt, ncclDouble, R.rank + 1, D->comm, s));
-        NCCLCHK(ncclRecv(f + a.lv.g.plane * a.own_hi, cnt, ncclDouble, R.rank + 1, D->comm, s));
+        NCCLCHK(ncclSend(f + a.lv.g.plane * (a.own_hi - H), cnt, ncclDouble, R.rank + 1, comm, s));
+        NCCLCHK(ncclRecv(f + a.lv.g.plane * (a.own_hi + skip), cnt, ncclDouble, R.rank + 1, comm, s));
     }
     if (R.rank > 0) {
-        NCCLCHK(ncclSend(f + a.lv.g.plane * a.own_lo, cnt, ncclDouble, R.rank - 1, D->comm, s));
-        NCCLCHK(ncclRecv(f + a.lv.g.plane * (a.own_lo - H), cnt, ncclDouble, R.rank - 1, D->comm, s));
+        NCCLCHK(ncclSend(f + a.lv.g.plane * (a.own_lo + skip), cnt, ncclDouble, R.rank - 1, comm, s));
+        NCCLCHK(ncclRecv(f + a.lv.g.plane * (a.own_lo - H), cnt, ncclDouble, R.rank - 1, comm, s));
     }
     NCCLCHK(ncclGroupEnd());
+    return MG3D_OK;
+}
+
+/* Start refreshing the u halos of level l behind everything queued on the compute stream so far, without
+ * holding the compute stream up; await_u() makes the compute stream wait for the arrival. */
+static int start_u_exchange(mg3d_dist *D, int l, int skip)
+{
+    if (D->P == 1)
+        return MG3D_OK;
+    if (!D->overlap)
+        return exchange_halo(D, MG3D_U, l, D->stream, skip);
+    HIPCHK(hipEventRecord(D->ev_ready, D->stream));
+    HIPCHK(hipStreamWaitEvent(D->comm_stream, D->ev_ready, 0));
+    CHK(exchange_halo(D, MG3D_U, l, D->comm_stream, skip));
+    HIPCHK(hipEventRecord(D->ev_u[l], D->comm_stream));
+    D->u_pending[l] = 1;
+    return MG3D_OK;
+}
+
+static int await_u(mg3d_dist *D, int l)
+{
+    if (D->u_pending[l]) {
+        HIPCHK(hipStreamWaitEvent(D->stream, D->ev_u[l], 0));
+        D->u_pending[l] = 0;
+    }
     return MG3D_OK;
 }
 
@@ -505,15 +566,11 @@ struct RestrictTarget { /* where a rank's restricted residual goes: coarse geome
 
 /* One smoothing stage on distributed level l for every local rank: iters x two colour passes, optional
  * residual (want_res 2: r stored or restricted on the fly into tgt[], 1: norm only, over OWNED planes, into
- * the rank's coarse->sumsq[0]).  Same launch policy as the single-domain path.
- *
- * xfield >= 0: the halo planes of that field (MG3D_U or MG3D_D) on this level must be refreshed from the
- * neighbours first.  The exchange runs on the communication stream while the first sweep launch works on the
- * interior planes [E, ni-E) -- those whose S-pass dependence cone (plus the pipeline's warm-up planes) does
- * not reach a halo plane: E = H + S + 3 -- and the two end windows follow once the halos have arrived.
- * All launches of the sweep read the same input and write disjoint planes of the alternate buffer. */
-static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const RestrictTarget *tgt, int xfield,
-                        bool zero_in = false /* u is identically zero: the first launch does not read it */)
+ * the rank's coarse->sumsq[0]).  Same launch policy as the single-domain path.  On entry the halos of u and
+ * d on this level are exact (H planes); nothing is exchanged in here. */
+static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const RestrictTarget *tgt,
+                        bool zero_in = false /* u is identically zero: the first launch does not read it */,
+                        bool refresh_u = false /* start the exchange of the u halos (planes 2..H) as soon as u is final */)
 {
     hipStream_t s = D->stream;
     const int c1 = post ? 0 : 1;
@@ -523,69 +580,41 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
         const int S = passes >= 4 ? 4 : passes;
         const bool last = passes - S == 0;
         const bool res = last && want_res != 0 && S != 4;
-        bool split = false;
-        const int E = D->H + S + 3;
-        if (first && xfield >= 0) {
-            split = D->overlap && D->P > 1 && !res && S > 0;
-            for (auto &R : D->rs)
-                if (SL(D, R, l).lv.g.ni - 2 * E < 24) /* too thin: three launches would cost more than they hide */
-                    split = false;
-            if (split) {
-                HIPCHK(hipEventRecord(D->ev_ready, s));
-                HIPCHK(hipStreamWaitEvent(D->comm_stream, D->ev_ready, 0));
-                CHK(exchange_halo(D, xfield, l, D->comm_stream));
-                HIPCHK(hipEventRecord(D->ev_done, D->comm_stream));
-            } else {
-                CHK(exchange_halo(D, xfield, l, s));
-            }
+        if (S == 0 && refresh_u) { /* u is final; the pure residual launch below reads owned +-1 only */
+            CHK(start_u_exchange(D, l, 1));
+            refresh_u = false;
         }
-        for (int phase = 0; phase < (split ? 2 : 1); phase++) {
-            if (split && phase == 1)
-                HIPCHK(hipStreamWaitEvent(s, D->ev_done, 0));
-            for (size_t ri = 0; ri < D->rs.size(); ri++) {
-                RankState &R = D->rs[ri];
-                SlabLevel &sl = SL(D, R, l);
-                Level &lv = sl.lv;
-                mg3d_ctx *cx = R.coarse;
-                const bool rst = res && tgt != nullptr && tgt[ri].dc != nullptr;
-                auto launch = [&](int i_lo, int i_hi) {
-                    return k_sweep(lv.g, (zero_in && first) ? nullptr : lv.f[MG3D_U], lv.f[MG3D_D], lv.alt,
+        for (size_t ri = 0; ri < D->rs.size(); ri++) {
+            RankState &R = D->rs[ri];
+            SlabLevel &sl = SL(D, R, l);
+            Level &lv = sl.lv;
+            mg3d_ctx *cx = R.coarse;
+            const bool rst = res && tgt != nullptr && tgt[ri].dc != nullptr;
+            /* output planes of a smoothing launch: the owned planes plus what the next consumer reads beyond
+             * them -- the residual/restriction behind a pre-smoother needs u on owned +-2, the top-level norm
+             * owned +-1; the remaining halo planes are refreshed by an exchange before anything reads them
+             * again.  Only the LAST smoothing launch of the stage may be trimmed: an earlier one feeds the next
+             * launch's whole dependence cone. */
+            const int margin = post ? 1 : 2;
+            const bool trim = last;
+            int w_lo = (!trim || sl.own_lo - margin < 0) ? 0 : sl.own_lo - margin;
+            int w_hi = (!trim || sl.own_hi + margin > lv.g.ni) ? lv.g.ni : sl.own_hi + margin;
+            /* a pure residual launch (S == 0) only has to produce what is consumed: the norm and the on-the-fly
+             * restriction need the owned planes (their neighbours come from the pipeline's warm-up / drain), a
+             * stored r one more plane on either side */
+            if (S == 0) {
+                const int pad = (want_res == 2 && !rst) ? 1 : 0;
+                w_lo = sl.own_lo - pad < 0 ? 0 : sl.own_lo - pad;
+                w_hi = sl.own_hi + pad > lv.g.ni ? lv.g.ni : sl.own_hi + pad;
+            }
+            const int np = k_sweep(lv.g, (zero_in && first) ? nullptr : lv.f[MG3D_U], lv.f[MG3D_D], lv.alt,
                                    (res && want_res == 2 && !rst) ? lv.f[MG3D_R] : nullptr,
                                    (res && want_res == 1) ? cx->partials : nullptr, /* the pre-smoothing norm is dropped (:1294) */
                                    MG3D_MAX_PARTIALS, lv.h, S, c1, res, s, sl.own_lo, sl.own_hi,
                                    rst ? tgt[ri].gc : nullptr, rst ? tgt[ri].dc : nullptr, rst ? tgt[ri].lo : -1,
-                                   rst ? tgt[ri].hi : -1, nullptr, nullptr, i_lo, i_hi);
-                };
-                /* output planes of a smoothing launch: the owned planes plus what the next consumer reads beyond
-                 * them -- the residual/restriction behind a pre-smoother needs u on owned +-2, the prolongation
-                 * to the next finer level and the top-level norm need owned +-1; the remaining halo planes are
-                 * refreshed by an exchange before anything reads them again */
-                const int margin = post ? 1 : 2;
-                /* only the LAST smoothing launch of the stage may be trimmed: an earlier one feeds the next
-                 * launch's whole dependence cone */
-                const bool trim = last;
-                const int o_lo = (!trim || sl.own_lo - margin < 0) ? 0 : sl.own_lo - margin;
-                const int o_hi = (!trim || sl.own_hi + margin > lv.g.ni) ? lv.g.ni : sl.own_hi + margin;
-                if (!split) {
-                    /* a pure residual launch (S == 0) only has to produce what is consumed: the norm and the
-                     * on-the-fly restriction need the owned planes (their neighbours come from the pipeline's
-                     * warm-up / drain), a stored r one more plane on either side */
-                    int w_lo = o_lo, w_hi = o_hi;
-                    if (S == 0) {
-                        const int pad = (want_res == 2 && !rst) ? 1 : 0;
-                        w_lo = sl.own_lo - pad < 0 ? 0 : sl.own_lo - pad;
-                        w_hi = sl.own_hi + pad > lv.g.ni ? lv.g.ni : sl.own_hi + pad;
-                    }
-                    const int np = launch(w_lo, w_hi);
-                    if (res && want_res == 1)
-                        k_fold(cx->partials, np, cx->sumsq, s);
-                } else if (phase == 0) {
-                    launch(E, lv.g.ni - E);
-                } else {
-                    launch(o_lo, E);
-                    launch(lv.g.ni - E, o_hi);
-                }
-            }
+                                   rst ? tgt[ri].hi : -1, nullptr, nullptr, w_lo, w_hi);
+            if (res && want_res == 1)
+                k_fold(cx->partials, np, cx->sumsq, s);
         }
         if (S > 0)
             for (auto &R : D->rs) {
@@ -599,6 +628,8 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
         passes -= S;
         first = false;
     }
+    if (refresh_u) /* the last launch smoothed and took the norm in one go */
+        CHK(start_u_exchange(D, l, 1));
     return MG3D_OK;
 }
 
@@ -610,8 +641,9 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
         if (!R.coarse->have_lu)
             return fail(MG3D_ERR_STATE, "mg3d_dist_vcycles: no coarse LU set (mg3d_dist_build_coarse)");
     std::vector<RestrictTarget> tgt(D->rs.size());
-    /* ---- down: distributed levels.  On entry the halos of d (all levels: upload / previous restriction's
-     * exchange below) and of the finest u (pending: exchanged by the stage itself) are exact. */
+    /* ---- down: distributed levels.  On entry the halos of d are exact on all levels (upload / the exchange
+     * that follows each restriction below) and those of the finest u have been refreshed since it last
+     * changed (upload, or the exchange started at the end of the previous cycle). */
     for (int l = L - 1; l >= ld; l--) {
         for (size_t ri = 0; ri < D->rs.size(); ri++) {
             RankState &R = D->rs[ri];
@@ -635,16 +667,21 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
         }
         const bool keep = D->rs[0].coarse->keep_r;
         std::vector<RestrictTarget> none(D->rs.size(), RestrictTarget{nullptr, nullptr, -1, -1});
-        /* :1282 + :1294 + :1310 (interior of the coarse rhs on the fly unless r is to be kept).  Halos to
-         * refresh first: the finest u (left stale by the previous cycle's post-smoother) or, below, this
-         * level's d (just restricted: only owned planes were produced). */
-        CHK(stage_smooth(D, l, 0, 2, keep ? none.data() : tgt.data(), l == L - 1 ? MG3D_U : MG3D_D, l < L - 1));
+        CHK(await_u(D, l));
+        /* :1282 + :1294 + :1310 (interior of the coarse rhs on the fly unless r is to be kept) */
+        CHK(stage_smooth(D, l, 0, 2, keep ? none.data() : tgt.data(), l < L - 1));
         for (size_t ri = 0; ri < D->rs.size(); ri++) {
             SlabLevel &sl = SL(D, D->rs[ri], l);
             k_restrict(sl.lv.g, sl.lv.f[MG3D_R], *tgt[ri].gc, tgt[ri].dc, s, tgt[ri].lo, tgt[ri].hi, !keep);
         }
+        /* u of this level is final until the prolongation on the way up: refresh its halos underneath the
+         * coarser levels */
+        CHK(start_u_exchange(D, l, 0));
+        /* the coarser level starts from its right-hand side at once: only owned planes were produced */
         if (l - 1 < ld)
             CHK(allgather_coarse_rhs(D));
+        else
+            CHK(exchange_halo(D, MG3D_D, l - 1, s));
     }
     /* ---- replicated levels: the ordinary V-cycle from level ld-1 (its guess zeroed first, :1258) */
     for (auto &R : D->rs) {
@@ -657,18 +694,26 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
     }
     /* ---- up */
     for (int l = ld; l < L; l++) {
+        /* :1331 on every local plane, halos included: the correction's halos (post-smoothed on owned +-1 only)
+         * are refreshed first, those of u have been under way since the pre-smoother */
+        if (l - 1 >= ld)
+            CHK(exchange_halo(D, MG3D_U, l - 1, s));
+        CHK(await_u(D, l));
         for (auto &R : D->rs) {
             SlabLevel &sl = SL(D, R, l);
             if (l - 1 >= ld) {
                 SlabLevel &sc = SL(D, R, l - 1);
-                k_prolong(sc.lv.g, sc.lv.f[MG3D_U], sl.lv.g, sl.lv.f[MG3D_U], s, sl.own_lo, sl.own_hi); /* :1331 */
+                k_prolong(sc.lv.g, sc.lv.f[MG3D_U], sl.lv.g, sl.lv.f[MG3D_U], s, 0, sl.lv.g.ni);
             } else {
                 Level &lc = R.coarse->lv[ld - 1];
-                k_prolong(lc.g, lc.f[MG3D_U], sl.lv.g, sl.lv.f[MG3D_U], s, sl.own_lo, sl.own_hi);
+                k_prolong(lc.g, lc.f[MG3D_U], sl.lv.g, sl.lv.f[MG3D_U], s, 0, sl.lv.g.ni);
             }
         }
-        /* :1341 (+ :1354 at the top level); u halos (prolongated on owned planes only) refreshed first */
-        CHK(stage_smooth(D, l, 1, l == L - 1 ? 1 : 0, nullptr, MG3D_U));
+        /* :1341 (+ :1354 at the top level): all H halo planes of u are exact here, the post-smoother uses up
+         * 2*nu of them.  The next cycle's pre-smoother wants fresh halos on the finest u: that exchange starts
+         * underneath the norm kernel, which reads the first halo plane on either side -- just produced
+         * exactly by the post-smoother, so the exchange leaves that plane alone. */
+        CHK(stage_smooth(D, l, 1, l == L - 1 ? 1 : 0, nullptr, false, l == L - 1));
     }
     CHK(reduce_norm(D, slot));
     hipError_t e = hipGetLastError();
@@ -677,9 +722,8 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
     return MG3D_OK;
 }
 
-/* after the last cycle (and before any download of halo-inclusive data) the finest u halos are refreshed;
- * inside a batch the next cycle's first stage does it, overlapped with its interior smoothing */
-static int dist_finish(mg3d_dist *D) { return exchange_halo(D, MG3D_U, D->L - 1, D->stream); }
+/* after the last cycle the compute stream joins the exchange of the finest u halos that the cycle started */
+static int dist_finish(mg3d_dist *D) { return await_u(D, D->L - 1); }
 
 extern "C" int mg3d_dist_vcycles(mg3d_dist *D, int count, double *norms)
 {

@@ -27,13 +27,20 @@ struct LuBand {
     int bw;       /* half bandwidth actually populated (max |i-j| with LU[i][j] != 0) */
     double *lcol; /* [n][bw]  lcol[j*bw+t] = LU[j+1+t][j]   (strictly lower, by column) */
     double *ucol; /* [n][bw]  ucol[j*bw+t] = LU[j-1-t][j]   (strictly upper, by column) */
-    double *diag; /* [n] */
+    int npad;     /* n rounded up to a multiple of 64 (identity rows appended) */
+    double *diag; /* [2*npad]: the diagonal, then RN(1/diagonal); 1 on the padding */
+    int fast_div; /* every diagonal entry lies in lu_div()'s safe window: the reciprocals may be used */
     /* lane-rotated copies for the single-wave solve (bw <= 64*rot_r): entry [j][64*q + l] is the
      * factor of the row lane l accumulates at step j: forward row j+1+((l-j-1)&63)+64q, backward row
      * j-1-((j-1-l)&63)-64q; zero outside the band / matrix */
     int rot_r;    /* 0 when not built */
     double *lrot; /* [n][64*rot_r] */
     double *urot; /* [n][64*rot_r] */
+    /* the same factors as ONE stream in the order the streamed solve consumes them: 2*npad/64 chunks of 64
+     * steps (forward steps j = 0..npad-1, then backward steps j = npad-1..0) plus two spare chunks the
+     * loaders may over-read; a step is 64 lanes x rot_r doubles, [lane][q] */
+    int stream_ch; /* 64 when built, else 0 */
+    double *stream;
 };
 
 #define MG3D_MAX_PARTIALS 32768
@@ -68,6 +75,8 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
             int i_lo = -1, int i_hi = -1 /* local output planes of this launch; default all.  Several launches
             with disjoint windows and the same vin/vout make up one sweep (overlap with halo exchange) */);
 /* b and x are level-0 grids in the padded layout g0; work holds 2n doubles */
+/* steps per chunk of the streamed solve for n unknowns and rot_r = R on the current device, 0 if it cannot run */
+int mg3d_lu_stream_chunk(int n, int R);
 void k_lu_solve(const LuBand &lu, const Geom &g0, const double *b_pad, double *x_pad, double *work, hipStream_t s);
 
 #endif

@@ -481,6 +481,32 @@ __device__ __forceinline__ double readlane_f64(double x, int lane_uniform)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+/* x = num / d, correctly rounded, with the reciprocal work taken off the dependency chain.  The compiler's
+ * own fp64 division (div_scale, rcp, two Newton steps, div_fmas, div_fixup) depends on the numerator from its
+ * first instruction: a dozen dependent operations per back-substitution step.  Here r = RN(1/d) comes from the
+ * host and the quotient is refined twice, q <- q + (num - d*q)*r with exact FMA residuals: after the first
+ * step q is within one ulp, and for a faithful q and a correctly rounded reciprocal the second step delivers
+ * RN(num/d) (Markstein's theorem; tests/c/div_check.c compares 10^8 operand pairs with the hardware quotient).
+ * Numerators outside a wide safe exponent window (and zeros, infinities, NaNs) take the ordinary division
+ * (`num` is wave-uniform, so that branch is too); a diagonal outside its window disables FAST altogether. */
+template <bool FAST>
+__device__ __forceinline__ double lu_div(double num, double d, double r)
+{
+    if (!FAST)
+        return num / d;
+    /* 2^-498 <= |num| < 2^499; the host vouches for |d| in [2^-460, 2^460] on the whole diagonal */
+    const unsigned e = (unsigned)(__double_as_longlong(num) >> 52) & 0x7ffu;
+    double q = num * r;
+    double rem = __builtin_fma(-d, q, num);
+    q = __builtin_fma(rem, r, q);
+    rem = __builtin_fma(-d, q, num);
+    q = __builtin_fma(rem, r, q);
+    /* +0 (every boundary unknown of a V-cycle's coarse right-hand side) also comes out right: +-0 by sign of d */
+    if (__builtin_expect(e - 525u >= 997u && __double_as_longlong(num) != 0ll, 0))
+        q = num / d;
+    return q;
+}
+
 /* One substitution pass of the single-wave solve.  Lane l owns the rows == l (mod 64); acc[0] is the
  * running sum of the row it finalises next, acc[1..] of the rows 64, 128, .. further on.  At step j
  * the owner lane (j & 63) turns its acc[0] into x[j]; v_readlane broadcasts it; every lane then adds
@@ -488,7 +514,7 @@ __device__ __forceinline__ double readlane_f64(double x, int lane_uniform)
  * pre-rotated so that lane l always reads element l of the step's column: no index arithmetic and no
  * predicates on the dependency chain  acc -> sub (-> div) -> readlane -> mul -> add.
  * Columns, rhs[j] and the diagonal are fetched U steps ahead (they do not depend on the solution). */
-template <int R, bool FWD>
+template <int R, bool FWD, bool FAST>
 __device__ __forceinline__ void lu_wave_pass(const LuBand &lu, int lane, const double *rhs, double *out,
                                              const double *dg)
 {
@@ -499,7 +525,7 @@ __device__ __forceinline__ void lu_wave_pass(const LuBand &lu, int lane, const d
 #pragma unroll
     for (int r = 0; r < R; r++)
         acc[r] = 0.;
-    double nxt[U][R], cur[U][R], rj[U], dj[U];
+    double nxt[U][R], cur[U][R], rj[U], dj[U], rdj[U];
     auto fetch = [&](int step, double(&dst)[R]) {
         int j = FWD ? step : n - 1 - step;
         j = j < 0 ? 0 : (j >= n ? n - 1 : j); /* steps past the end: any valid column, never used */
@@ -522,6 +548,7 @@ __device__ __forceinline__ void lu_wave_pass(const LuBand &lu, int lane, const d
             const bool in = step < n;
             rj[u] = in ? rhs[j] : 0.; /* uniform address: LDS broadcast */
             dj[u] = (!FWD && in) ? dg[j] : 1.;
+            rdj[u] = (!FWD && in) ? dg[n + j] : 1.;
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
@@ -533,12 +560,12 @@ __device__ __forceinline__ void lu_wave_pass(const LuBand &lu, int lane, const d
                 break;
             const int j = FWD ? step : n - 1 - step;
             const int owner = j & 63;
-            double cand = rj[u] - acc[0]; /* gauss_elim.h:46 / :57 */
+            double xj = readlane_f64(rj[u] - acc[0], owner); /* gauss_elim.h:46 / :57 */
             if (!FWD)
-                cand = cand / dj[u];
-            const double xj = readlane_f64(cand, owner);
-            out[j] = xj; /* every lane stores the same value to the same LDS word */
+                xj = lu_div<FAST>(xj, dj[u], rdj[u]);
             const bool own = lane == owner;
+            if (own) /* one lane: 64 lanes storing to the same LDS word are serialised by the LDS */
+                out[j] = xj;
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const double base = own ? (r + 1 < R ? acc[r + 1] : 0.) : acc[r];
@@ -554,7 +581,7 @@ __global__ void __launch_bounds__(64) lu_solve_wave_kernel(LuBand lu, Geom g0, c
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x, n = lu.n;
-    double *b = lds, *z = lds + n, *dg = lds + 2 * n; /* x overwrites b */
+    double *b = lds, *z = lds + n, *dg = lds + 2 * n; /* x overwrites b; dg = diagonal, then its reciprocals */
     const int NN = g0.nj * g0.nk;
     auto pad_of = [&](int p) -> long long {
         const int i = p / NN, rem = p - i * NN;
@@ -564,14 +591,266 @@ __global__ void __launch_bounds__(64) lu_solve_wave_kernel(LuBand lu, Geom g0, c
     for (int p = lane; p < n; p += WAVE) {
         b[p] = b_pad[pad_of(p)];
         dg[p] = lu.diag[p];
+        dg[n + p] = lu.diag[lu.npad + p];
     }
     __syncthreads();
-    lu_wave_pass<R, true>(lu, lane, b, z, dg);
+    lu_wave_pass<R, true, false>(lu, lane, b, z, dg);
     __syncthreads();
-    lu_wave_pass<R, false>(lu, lane, z, b, dg);
+    if (lu.fast_div)
+        lu_wave_pass<R, false, true>(lu, lane, z, b, dg);
+    else
+        lu_wave_pass<R, false, false>(lu, lane, z, b, dg);
     __syncthreads();
     for (int p = lane; p < n; p += WAVE)
         x_pad[pad_of(p)] = b[p];
+}
+
+/* Streamed variant of the single-wave solve: the shipped one for narrow bands.  Same substitution, same
+ * dependency chain (sub -> readlane -> [divide] -> mul -> add); what changes is everything around the chain.
+ * tools/lu_step_probe.hip prices a step of the plain pass at ~220 cycles of which the chain is 48: every LDS
+ * or global access inside the step costs ~45 cycles of issue.  Here a step touches no memory at all:
+ *   - the system is padded to a multiple of 64 unknowns (identity rows) and walked in chunks of 64 steps, in
+ *     which every lane owns exactly one unknown: its right-hand side, diagonal and reciprocal sit in
+ *     registers (one coalesced LDS read per chunk), its result leaves by one coalesced LDS write per chunk;
+ *   - the factors of 32 steps at a time are read from LDS into registers before the steps run;
+ *   - two loader waves of the same workgroup stream the factors -- stored in consumption order, forward
+ *     steps then backward steps -- from HBM into a two-slot LDS ring, one chunk per slot, two chunks ahead
+ *     (one in their registers, one in LDS); one workgroup barrier per chunk hands a filled slot to the solver
+ *     wave and a used one back.  Three waves, one per SIMD: each may use the whole register file. */
+/* lane LANE of `vec` <- the wave-uniform value / zero.  v_writelane_b32 by hand (this compiler has no builtin
+ * for it).  The hazard recogniser does not look inside an asm block, so the block carries its own wait states
+ * for a scalar source that a VALU instruction (v_readlane) has just written; the lane select is an inline
+ * constant, which takes the instruction's other manual-wait-state rule out of play. */
+template <int LANE>
+__device__ __forceinline__ double writelane_f64(double vec, double uniform)
+{
+    const long long v = __double_as_longlong(vec), u = __double_as_longlong(uniform);
+    int vlo = (int)(v & 0xffffffffll), vhi = (int)(v >> 32);
+    const int ulo = __builtin_amdgcn_readfirstlane((int)(u & 0xffffffffll));
+    const int uhi = __builtin_amdgcn_readfirstlane((int)(u >> 32));
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+        : "+v"(vlo), "+v"(vhi)
+        : "s"(ulo), "s"(uhi), "n"(LANE));
+    return __longlong_as_double(((long long)vhi << 32) | (unsigned int)vlo);
+}
+
+/* Given readlane(f(a, b)) the compiler rewrites it into f(readlane(a), readlane(b)) -- three VALU->SGPR
+ * crossings on the dependency chain instead of one.  Passing the value through an empty asm keeps the
+ * arithmetic per lane; the readlane itself stays the builtin, so the compiler still places the wait states the
+ * instruction needs around it. */
+__device__ __forceinline__ double opaque_f64(double x)
+{
+    const long long b = __double_as_longlong(x);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+/* lane LANE of `keep` <- lane LANE of `x`, nothing else touched: two moves under a one-lane EXEC mask (the wave
+ * runs with all lanes on; no scalar register is involved, so no VALU<->SGPR crossing) */
+template <int LANE>
+__device__ __forceinline__ double keeplane_f64(double keep, double x)
+{
+    const long long k = __double_as_longlong(keep), b = __double_as_longlong(x);
+    int klo = (int)(k & 0xffffffffll), khi = (int)(k >> 32);
+    const int xlo = (int)(b & 0xffffffffll), xhi = (int)(b >> 32);
+    asm("s_lshl_b64 exec, 1, %4\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\ts_mov_b64 exec, -1"
+        : "+v"(klo), "+v"(khi)
+        : "v"(xlo), "v"(xhi), "n"(LANE));
+    return __longlong_as_double(((long long)khi << 32) | (unsigned int)klo);
+}
+
+template <int LANE>
+__device__ __forceinline__ double zerolane_f64(double vec)
+{
+    const long long v = __double_as_longlong(vec);
+    int vlo = (int)(v & 0xffffffffll), vhi = (int)(v >> 32);
+    asm("v_writelane_b32 %0, 0, %2\n\tv_writelane_b32 %1, 0, %2" : "+v"(vlo), "+v"(vhi) : "n"(LANE));
+    return __longlong_as_double(((long long)vhi << 32) | (unsigned int)vlo);
+}
+
+template <int R, bool FWD, bool FAST, int HALF, int U0>
+__device__ __forceinline__ void lu_stream_steps(const double (&f)[32][R], double myrhs, double mydg, double myrdg,
+                                                double &mine, double &mynum, double &A, double &B)
+{
+    if constexpr (U0 < 32) {
+        constexpr int owner = FWD ? HALF * 32 + U0 : 63 - (HALF * 32 + U0); /* j & 63: chunks are 64-aligned in j */
+        const double num = myrhs - A; /* gauss_elim.h:46 / :57; the owner's lane holds the real one */
+        double xj;
+        if (FWD) {
+            xj = readlane_f64(num, owner);
+        } else if (!FAST) {
+            xj = readlane_f64(num, owner) / readlane_f64(mydg, owner);
+        } else {
+            /* lu_div()'s sequence, but every lane divides its own (mostly meaningless) numerator by its own
+             * diagonal and only the quotient is broadcast: one VALU->SGPR crossing on the chain.  The owner's
+             * numerator is kept; whether it was inside lu_div's window is checked once per chunk. */
+            double q = num * myrdg;
+            double rem = __builtin_fma(-mydg, q, num);
+            q = __builtin_fma(rem, myrdg, q);
+            rem = __builtin_fma(-mydg, q, num);
+            q = __builtin_fma(rem, myrdg, q);
+            xj = readlane_f64(opaque_f64(q), owner);
+            mynum = keeplane_f64<owner>(mynum, num);
+        }
+        mine = writelane_f64<owner>(mine, xj);
+        A = zerolane_f64<owner>(A);
+        A = A + f[U0][0] * xj; /* sum += LU[i][j]*x[j], gauss_elim.h:41,55 */
+        if (R == 2)
+            B = B + f[U0][R - 1] * xj;
+        lu_stream_steps<R, FWD, FAST, HALF, U0 + 1>(f, myrhs, mydg, myrdg, mine, mynum, A, B);
+    }
+}
+
+/* 32 steps of a chunk.  A lane's two running sums are called A and B.  At the start of a chunk A belongs to
+ * the row the lane finalises next and B to the row 64 further on; a lane finalises exactly once per chunk (at
+ * the step whose unknown it owns), after which B is its next row and A starts from zero for the row 128 on.
+ * The factor stream stores each step's pair already in (A's, B's) order for every lane, so the step is
+ * select-free:  x = broadcast(rhs - A) [/ diagonal];  owner: result <- x, A <- 0;  A += fa*x;  B += fb*x.
+ * At the end of the chunk every lane has switched, and the caller exchanges the names. */
+template <int R, bool FWD, bool FAST, int HALF>
+__device__ __forceinline__ void lu_stream_half(const double *slot, int lane, double myrhs, double mydg, double myrdg,
+                                               double &mine, double &mynum, double &A, double &B)
+{
+    double f[32][R];
+#pragma unroll
+    for (int u = 0; u < 32; u++)
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            f[u][r] = slot[((HALF * 32 + u) * 64 + lane) * R + r];
+    /* all 32 reads in flight before the first step: left to itself the scheduler sinks each one to its use,
+     * behind a full lgkmcnt wait, and the step pays the LDS latency */
+    __builtin_amdgcn_sched_barrier(0);
+    lu_stream_steps<R, FWD, FAST, HALF, 0>(f, myrhs, mydg, myrdg, mine, mynum, A, B);
+}
+
+template <int R, bool FWD, bool FAST>
+__device__ __forceinline__ void lu_stream_pass(const double *ring, int first_chunk, int nch, int npad, int lane,
+                                               const double *rhs, double *out, const double *dg)
+{
+    constexpr int CD = 64 * 64 * R;
+    double A = 0., B = 0.;
+    for (int cc = 0; cc < nch; cc++) {
+        const double *slot = ring + ((first_chunk + cc) & 1) * CD;
+        const int jl = (FWD ? cc * 64 : npad - 64 * (cc + 1)) + lane; /* the unknown this lane owns in the chunk */
+        const double myrhs = rhs[jl], mydg = FWD ? 1. : dg[jl], myrdg = FWD ? 1. : dg[npad + jl];
+        double mine = 0., mynum = 1.;
+        const double A0 = A, B0 = B;
+        lu_stream_half<R, FWD, FAST, 0>(slot, lane, myrhs, mydg, myrdg, mine, mynum, A, B);
+        lu_stream_half<R, FWD, FAST, 1>(slot, lane, myrhs, mydg, myrdg, mine, mynum, A, B);
+        if (!FWD && FAST) {
+            /* a numerator outside lu_div's window (never seen in a V-cycle: they are ordinary numbers or +0):
+             * this chunk again, with the ordinary division */
+            const unsigned e = (unsigned)(__double_as_longlong(mynum) >> 52) & 0x7ffu;
+            const bool bad = e - 525u >= 997u && __double_as_longlong(mynum) != 0ll;
+            if (__builtin_expect(__any(bad), 0)) {
+                A = A0;
+                B = B0;
+                lu_stream_half<R, FWD, false, 0>(slot, lane, myrhs, mydg, myrdg, mine, mynum, A, B);
+                lu_stream_half<R, FWD, false, 1>(slot, lane, myrhs, mydg, myrdg, mine, mynum, A, B);
+            }
+        }
+        out[jl] = mine;
+        if (R == 2) {
+            const double t = A;
+            A = B;
+            B = t;
+        }
+        __syncthreads();
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(192) lu_solve_stream_kernel(LuBand lu, Geom g0, const double *__restrict__ b_pad,
+                                                             double *__restrict__ x_pad)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int CD = 64 * 64 * R;  /* doubles per chunk */
+    constexpr int NV = CD / 2 / 128; /* 16-byte vectors per loader lane per chunk (two loader waves) */
+    const int tid = threadIdx.x, lane = tid & 63, n = lu.n, npad = lu.npad;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nch = npad / 64, T = 2 * nch;
+    double *ring = lds, *b = lds + 2 * CD, *z = b + npad, *dg = z + npad; /* x overwrites b; dg: diagonal, reciprocals */
+    const int NN = g0.nj * g0.nk;
+    auto pad_of = [&](int p) -> long long {
+        const int i = p / NN, rem = p - i * NN;
+        const int j = rem / g0.nk, k = rem - j * g0.nk;
+        return g0.plane * i + (long long)g0.pitch * j + k;
+    };
+    for (int p = tid; p < npad; p += 192) {
+        b[p] = p < n ? b_pad[pad_of(p)] : 0.;
+        dg[p] = lu.diag[p];
+        dg[npad + p] = lu.diag[npad + p];
+    }
+    if (wave != 0) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const int at = (wave - 1) * 64 + lane;
+        const v2d *src = reinterpret_cast<const v2d *>(lu.stream);
+        v2d *dst = reinterpret_cast<v2d *>(ring);
+        v2d regs[NV];
+#pragma unroll
+        for (int t = 0; t < NV; t++)
+            regs[t] = src[t * 128 + at];
+#pragma unroll
+        for (int t = 0; t < NV; t++)
+            dst[t * 128 + at] = regs[t];
+#pragma unroll
+        for (int t = 0; t < NV; t++)
+            regs[t] = src[CD / 2 + t * 128 + at];
+        __syncthreads();
+        for (int c = 0; c < T; c++) {
+            v2d *d2 = dst + ((c + 1) & 1) * (CD / 2);
+#pragma unroll
+            for (int t = 0; t < NV; t++)
+                d2[t * 128 + at] = regs[t];
+            const v2d *s2 = src + (long long)(c + 2) * (CD / 2);
+#pragma unroll
+            for (int t = 0; t < NV; t++)
+                regs[t] = s2[t * 128 + at];
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        lu_stream_pass<R, true, false>(ring, 0, nch, npad, lane, b, z, dg);
+        if (lu.fast_div)
+            lu_stream_pass<R, false, true>(ring, nch, nch, npad, lane, z, b, dg);
+        else
+            lu_stream_pass<R, false, false>(ring, nch, nch, npad, lane, z, b, dg);
+    }
+    __syncthreads();
+    for (int p = tid; p < n; p += 192)
+        x_pad[pad_of(p)] = b[p];
+}
+
+static size_t lu_stream_lds(int npad, int R) { return sizeof(double) * (2 * (size_t)64 * 64 * R + 4 * (size_t)npad); }
+
+int mg3d_lu_stream_chunk(int n, int R)
+{
+    static const bool off = getenv("MG3D_LU_STREAM") && getenv("MG3D_LU_STREAM")[0] == '0';
+    if (off || R < 1 || R > 2)
+        return 0;
+    int dev = 0, max_lds = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess)
+        return 0;
+    return lu_stream_lds((n + 63) / 64 * 64, R) <= (size_t)max_lds ? 64 : 0;
+}
+
+template <int R>
+static bool launch_lu_stream(const LuBand &lu, const Geom &g0, const double *b_pad, double *x_pad, hipStream_t s)
+{
+    const size_t lds = lu_stream_lds(lu.npad, R);
+    static bool ready = false, ok = false;
+    if (!ready) { /* a slot ring beyond 64 KB has to be asked for once per kernel */
+        ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&lu_solve_stream_kernel<R>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess || lds <= 65536;
+        (void)hipGetLastError();
+        ready = true;
+    }
+    if (!ok)
+        return false;
+    hipLaunchKernelGGL((lu_solve_stream_kernel<R>), dim3(1), dim3(192), lds, s, lu, g0, b_pad, x_pad);
+    return true;
 }
 
 /* Generic fallback for wide bands (coarse grids beyond 9^3): one 1024-thread
@@ -622,7 +901,11 @@ __global__ void __launch_bounds__(1024) lu_solve_block_kernel(LuBand lu, Geom g0
 void k_lu_solve(const LuBand &lu, const Geom &g0, const double *b_pad, double *x_pad, double *work, hipStream_t s)
 {
     double *z = work, *acc = work + lu.n;
-    const size_t lds = sizeof(double) * 3 * (size_t)lu.n;
+    const size_t lds = sizeof(double) * 4 * (size_t)lu.n;
+    if (lu.stream_ch == 64 && lu.rot_r == 2 && launch_lu_stream<2>(lu, g0, b_pad, x_pad, s))
+        return;
+    if (lu.stream_ch == 64 && lu.rot_r == 1 && launch_lu_stream<1>(lu, g0, b_pad, x_pad, s))
+        return;
     if (lu.rot_r == 1)
         hipLaunchKernelGGL(lu_solve_wave_kernel<1>, dim3(1), dim3(64), lds, s, lu, g0, b_pad, x_pad);
     else if (lu.rot_r == 2)

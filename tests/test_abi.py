@@ -114,3 +114,18 @@ def test_compute_fails_loudly_without_gpu():
     assert L.mg3d_host_smooth(P(a), P(a), 3, 0.5, 1, 0) == 2
     with pytest.raises(M.Mg3dError):
         M.Solver(5, 3, 2)
+
+
+def test_lu_division_sequence_is_exact(tmp_path):
+    """The twice-refined quotient of csrc/mg3d_kernels.hip:lu_div equals the IEEE quotient bit for bit
+    (tests/c/div_check.c: hard significands, quotients beside rounding boundaries, random operands)."""
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c", "div_check.c")
+    exe = str(tmp_path / "div_check")
+    with open("/proc/cpuinfo") as f:
+        hw_fma = " fma " in f.read()
+    flags = ["-mfma"] if hw_fma else []
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", *flags, "-o", exe, src, "-lm"], check=True)
+    r = subprocess.run([exe, "20000000" if hw_fma else "300000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    assert "mismatches 0" in r.stdout

@@ -45,20 +45,22 @@ class Slab:
         self.u, self.d, self.r = (np.zeros((self.ni, self.N, self.N)) for _ in range(3))
 
 
-def exchange(field, sl, r, P, H):
-    """exchange_halo of mg3d_dist.hip: last/first H owned planes to the upper/lower neighbour's halo."""
+def exchange(field, sl, r, P, H, skip=0):
+    """exchange_halo of mg3d_dist.hip: halo planes skip+1..H (counted from the owned planes) from the
+    neighbours' outermost owned planes."""
     a = getattr(sl, field)
     reqs, bufs = [], []
+    n = H - skip
     if r + 1 < P:
-        reqs.append(dist.isend(torch.from_numpy(a[sl.own_hi - H:sl.own_hi].copy()), r + 1))
-        up = torch.empty((H, sl.N, sl.N), dtype=torch.float64)
+        reqs.append(dist.isend(torch.from_numpy(a[sl.own_hi - H:sl.own_hi - skip].copy()), r + 1))
+        up = torch.empty((n, sl.N, sl.N), dtype=torch.float64)
         reqs.append(dist.irecv(up, r + 1))
-        bufs.append((up, slice(sl.own_hi, sl.own_hi + H)))
+        bufs.append((up, slice(sl.own_hi + skip, sl.own_hi + H)))
     if r > 0:
-        reqs.append(dist.isend(torch.from_numpy(a[sl.own_lo:sl.own_lo + H].copy()), r - 1))
-        dn = torch.empty((H, sl.N, sl.N), dtype=torch.float64)
+        reqs.append(dist.isend(torch.from_numpy(a[sl.own_lo + skip:sl.own_lo + H].copy()), r - 1))
+        dn = torch.empty((n, sl.N, sl.N), dtype=torch.float64)
         reqs.append(dist.irecv(dn, r - 1))
-        bufs.append((dn, slice(sl.own_lo - H, sl.own_lo)))
+        bufs.append((dn, slice(sl.own_lo - H, sl.own_lo - skip)))
     for q in reqs:
         q.wait()
     for t, s in bufs:
@@ -96,6 +98,9 @@ def worker(r, P, port, c, L, nu, cycles, out_path):
                 sl.u[:] = 0.0
             S.smooth(sl.u, sl.d, hs[l], nu, False, sl.ig0, sl.N)
             S.residual(sl.u, sl.d, hs[l], sl.r, sl.ig0, sl.N)
+            # u of this level is final until the way up: its halos travel now (on the GPU: underneath the
+            # coarser levels, on the communication stream)
+            exchange("u", sl, r, P, H)
             if l - 1 >= ld:
                 sc = lv[l - 1]
                 S.restrict_planes(sl.r, sl.ig0, sl.N, sc.d, sc.ig0, sc.N, sc.own_lo, sc.own_hi)
@@ -117,16 +122,21 @@ def worker(r, P, port, c, L, nu, cycles, out_path):
         O.lib().orc_vcycle(Hc.ptrs(Hc.u), Hc.ptrs(Hc.d), Hc.ptrs(Hc.r), hs[ld - 1], ld - 1, L, nu, Hc.N[ld - 1], O.P(LU))
         for l in range(ld, L):  # ---- up
             sl = lv[l]
+            # the correction is applied to every local plane, halos included: both operands have exact halos
             if l - 1 >= ld:
                 sc = lv[l - 1]
-                S.prolong_planes(sc.u, sc.ig0, sc.N, sl.u, sl.ig0, sl.N, sl.own_lo, sl.own_hi)
+                exchange("u", sc, r, P, H)
+                S.prolong_planes(sc.u, sc.ig0, sc.N, sl.u, sl.ig0, sl.N, 0, sl.ni)
             else:
                 Nc = Hc.N[ld - 1]
-                S.prolong_planes(Hc.u[ld - 1].reshape(Nc, Nc, Nc), 0, Nc, sl.u, sl.ig0, sl.N, sl.own_lo, sl.own_hi)
-            exchange("u", sl, r, P, H)
-            S.smooth(sl.u, sl.d, hs[l], nu, True, sl.ig0, sl.N)
-        ss = S.residual(top.u, top.d, hs[L - 1], None, top.ig0, top.N, top.own_lo, top.own_hi)
-        exchange("u", top, r, P, H)
+                S.prolong_planes(Hc.u[ld - 1].reshape(Nc, Nc, Nc), 0, Nc, sl.u, sl.ig0, sl.N, 0, sl.ni)
+            S.smooth(sl.u, sl.d, hs[l], nu, True, sl.ig0, sl.N)  # no exchange: uses up 2*nu of the H halo planes
+        # on the GPU the exchange below runs underneath the norm kernel, which reads the first halo plane:
+        # that plane is left as the post-smoother produced it (exact), planes 2..H are refreshed
+        top_before = top.u.copy()
+        exchange("u", top, r, P, H, skip=1)
+        ss = S.residual(top_before, top.d, hs[L - 1], None, top.ig0, top.N, top.own_lo, top.own_hi)
+        assert ss == S.residual(top.u, top.d, hs[L - 1], None, top.ig0, top.N, top.own_lo, top.own_hi)
         parts = [torch.zeros(1, dtype=torch.float64) for _ in range(P)]
         dist.all_gather(parts, torch.tensor([ss], dtype=torch.float64))
         norms.append(float(np.sqrt(sum(float(p) for p in parts))))

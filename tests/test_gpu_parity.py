@@ -136,6 +136,38 @@ def test_lu_solve_matches_golden_and_oracle(c):
     assert np.array_equal(x, G[f"lu_x_{c}"])
 
 
+@pytest.mark.parametrize("c", [5, 9])
+@pytest.mark.parametrize("kind", ["tiny", "huge", "zeros", "negzero", "mixed"])
+def test_lu_solve_numerators_outside_the_fast_division_window(c, kind):
+    """The back substitution divides through a host reciprocal with two FMA refinements (lu_div) while the
+    numerator lies in a wide exponent window, and falls back to the ordinary division chunk-wise otherwise.
+    Right-hand sides that leave the window (denormals, 1e200, signed zeros) must still match the oracle bit
+    for bit, signs of zero included."""
+    n = c ** 3
+    h = 1.0 / (c - 1)
+    A = np.zeros(n * n)
+    O.lib().orc_coarse_matrix(O.P(A), c, h)
+    O.lib().orc_lu_factor(O.P(A), n)
+    rng = np.random.default_rng(c)
+    b = rng.uniform(-1, 1, n)
+    if kind == "tiny":
+        b *= 1e-308
+    elif kind == "huge":
+        b *= 1e200
+    elif kind == "zeros":
+        b[rng.random(n) < 0.7] = 0.0
+    elif kind == "negzero":
+        b[rng.random(n) < 0.7] = -0.0
+    else:
+        sel = rng.integers(0, 5, n)
+        b = np.where(sel == 0, b * 1e-310, np.where(sel == 1, b * 1e180, np.where(sel == 2, -0.0, np.where(sel == 3, 0.0, b))))
+    want, got = np.zeros(n), np.zeros(n)
+    O.lib().orc_lu_solve(O.P(A), n, O.P(b), O.P(want))
+    check(M.lib().mg3d_host_lu_solve(P(A), n, P(b), P(got)))
+    assert np.array_equal(got, want)
+    assert np.array_equal(np.signbit(got), np.signbit(want))
+
+
 def test_lu_solve_dense_random_matrix():
     # a full (non-banded) diagonally dominant factor: exercises the wide-band block kernel
     n = 200
