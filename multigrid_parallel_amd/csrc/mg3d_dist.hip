@@ -66,10 +66,16 @@
 /* ------------------------------------------------------------------------------------------ plan */
 extern "C" int mg3d_slab_halo(int smooth_iters) { return 2 * smooth_iters + 2; }
 
-/* first distributed level: every rank must own at least max(8, halo) planes there */
+/* first distributed level: every rank must own at least max(8, halo) planes there.  MG3D_SLAB_MIN_PLANES raises
+ * the 8 (a knob for real xGMI: below some slab thickness replicating a level costs less than its exchanges) */
 extern "C" int mg3d_slab_first_level(int coarse_pts, int num_levels, int nranks, int halo)
 {
-    const int need = halo > 8 ? halo : 8;
+    static const int floor_planes = [] {
+        const char *e = getenv("MG3D_SLAB_MIN_PLANES");
+        const int v = e ? atoi(e) : 0;
+        return v > 8 ? v : 8;
+    }();
+    const int need = halo > floor_planes ? halo : floor_planes;
     for (int l = 1; l < num_levels; l++) {
         const long long n1 = ((long long)(coarse_pts - 1) << l);
         if (n1 / nranks >= need)
