@@ -4,7 +4,7 @@
  * Partition: the reference's OpenMP path already splits every operator over the slowest index i
  * (`#pragma omp for` over i, mg_3d.h:658-659); its implicit barriers become plane exchanges here.
  * Rank r owns the global planes [b_l(r), b_l(r+1)) of level l, with b_{l+1} = 2*b_l, so coarse plane ic
- * and fine plane 2*ic always have the same owner.  Levels too small to give every rank 8 planes are
+ * and fine plane 2*ic always have the same owner.  Levels too small to give every rank 16 planes are
  * REPLICATED: the restricted right-hand side is all-gathered once per cycle and every rank runs the
  * remaining levels (and the gauss_elim.h direct solve) redundantly on identical data -- what a gather to
  * rank 0 followed by a broadcast would deliver, bit for bit, with one collective instead of two.
@@ -66,15 +66,16 @@
 /* ------------------------------------------------------------------------------------------ plan */
 extern "C" int mg3d_slab_halo(int smooth_iters) { return 2 * smooth_iters + 2; }
 
-/* first distributed level: every rank must own at least max(8, halo) planes there.  MG3D_SLAB_MIN_PLANES raises
- * the 8 (a knob for real xGMI: below some slab thickness replicating a level costs less than its exchanges) */
+/* first distributed level: every rank must own at least max(16, halo) planes there.  Thinner slabs are launch-
+ * latency bound either way (a 65^3 level costs a rank the same whether it sweeps 8+12 planes or all 65), so
+ * replicating them is free in kernel time and saves three exchanges per level and cycle (loopback rehearsal, 8
+ * ranks: 9.16 ms per cycle with 65^3 replicated against 9.22 distributed; 129^3 replicated as well: 9.61).
+ * MG3D_SLAB_MIN_PLANES overrides the 16 (minimum 8): a knob for tuning on real xGMI. */
 extern "C" int mg3d_slab_first_level(int coarse_pts, int num_levels, int nranks, int halo)
 {
-    static const int floor_planes = [] {
-        const char *e = getenv("MG3D_SLAB_MIN_PLANES");
-        const int v = e ? atoi(e) : 0;
-        return v > 8 ? v : 8;
-    }();
+    const char *e = getenv("MG3D_SLAB_MIN_PLANES"); /* read per call: host-side planning only */
+    const int v = e ? atoi(e) : 16;
+    const int floor_planes = v > 8 ? v : 8;
     const int need = halo > floor_planes ? halo : floor_planes;
     for (int l = 1; l < num_levels; l++) {
         const long long n1 = ((long long)(coarse_pts - 1) << l);

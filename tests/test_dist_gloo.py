@@ -157,8 +157,9 @@ def worker(r, P, port, c, L, nu, cycles, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("c,L,nu,P", [(5, 5, 2, 2), (5, 5, 1, 2), (3, 6, 2, 3)])
-def test_slab_schedule_over_gloo(tmp_path, c, L, nu, P):
+@pytest.mark.parametrize("c,L,nu,P,min_planes", [(5, 5, 2, 2, 16), (5, 5, 1, 2, 8), (3, 6, 2, 3, 8), (3, 6, 2, 3, 16)])
+def test_slab_schedule_over_gloo(tmp_path, monkeypatch, c, L, nu, P, min_planes):
+    monkeypatch.setenv("MG3D_SLAB_MIN_PLANES", str(min_planes))  # 8: thin slabs, three distributed levels
     cycles = 3
     out = str(tmp_path / "res.npz")
     mp.spawn(worker, args=(P, free_port(), c, L, nu, cycles, out), nprocs=P, join=True)
@@ -173,6 +174,7 @@ def test_partition_properties():
     """Cuts are nested (coarse plane ic and fine plane 2*ic share an owner), cover the level, and leave every rank
     at least a halo's worth of planes."""
     lib = M.lib()
+    os.environ.pop("MG3D_SLAB_MIN_PLANES", None)
     for (c, L, nu, P) in [(9, 7, 2, 8), (9, 7, 2, 4), (9, 7, 2, 2), (5, 6, 3, 3), (9, 8, 2, 8), (3, 7, 1, 5)]:
         H = lib.mg3d_slab_halo(nu)
         assert H == 2 * nu + 2
@@ -191,5 +193,5 @@ def test_partition_properties():
                 else:
                     assert lo % 2 == 0
             assert prev == N
-    assert lib.mg3d_slab_first_level(9, 7, 8, 6) == 3  # 513^3 on 8 GPUs: 65^3 and up distributed
+    assert lib.mg3d_slab_first_level(9, 7, 8, 6) == 4  # 513^3 on 8 GPUs: 129^3 and up distributed (>= 16 planes per rank)
     assert owned(9, 7, 8, 6, 6, 3) == (192, 256)

@@ -18,9 +18,14 @@ def single(c, L, nu, cycles):
         return norms, s.download(MG3D_U, L - 1)
 
 
+@pytest.mark.parametrize("min_planes", [8, 16])
 @pytest.mark.parametrize("c,L,nu,P", [(5, 5, 2, 2), (5, 5, 2, 4), (5, 5, 2, 8), (9, 5, 2, 8), (9, 5, 2, 2), (5, 5, 1, 4),
                                       (5, 5, 3, 2), (3, 6, 2, 3), (9, 4, 2, 4), (9, 6, 2, 4)])
-def test_slab_vcycles_match_single_domain(c, L, nu, P):
+def test_slab_vcycles_match_single_domain(monkeypatch, c, L, nu, P, min_planes):
+    """min_planes 8: thin slabs, as many distributed levels as possible; 16: the default replication threshold."""
+    if ((c - 1) << (L - 1)) // P < max(min_planes, 2 * nu + 2):
+        pytest.skip("no level gives every rank that many planes")
+    monkeypatch.setenv("MG3D_SLAB_MIN_PLANES", str(min_planes))
     cycles = 6
     want_norms, want_u = single(c, L, nu, cycles)
     with M.DistSolver(c, L, nu, nranks=P) as d:
@@ -32,7 +37,8 @@ def test_slab_vcycles_match_single_domain(c, L, nu, P):
     np.testing.assert_allclose(norms, want_norms, rtol=1e-11, atol=0)
 
 
-def test_slab_intermediate_levels_match_single_domain():
+def test_slab_intermediate_levels_match_single_domain(monkeypatch):
+    monkeypatch.setenv("MG3D_SLAB_MIN_PLANES", "8")
     c, L, nu, P = 9, 5, 2, 4
     with M.Solver(c, L, nu) as s, M.DistSolver(c, L, nu, nranks=P) as d:
         s.set_keep_residual(True)
@@ -64,8 +70,8 @@ def test_single_rank_rccl_communicator():
 
 
 def test_overlap_and_sequential_exchange_agree(monkeypatch):
-    """MG3D_NO_OVERLAP=1 keeps every halo exchange on the compute stream; by default the exchange runs on a second
-    stream while the interior planes are smoothed.  129^3 on 2 ranks: the split path is taken on two levels."""
+    """MG3D_NO_OVERLAP=1 keeps every halo exchange on the compute stream; by default the large u exchanges run on
+    a second stream underneath the coarser levels and the norm kernel."""
     res = []
     for flag in ("0", "1"):
         monkeypatch.setenv("MG3D_NO_OVERLAP", flag)
