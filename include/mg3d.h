@@ -189,6 +189,31 @@ double mg3d_l2norm_host(const double *d, long n);
 void mg3d_smooth_edges_host(double *u, int N);
 int mg3d_write_vtk(const char *file_name, const double *grid, double h, int N);
 
+/* ---- single precision / damped Jacobi / F-cycle variant (BASELINE configs[4]) --------------------------
+ * PARITY UNPINNED: the reference has no fp32 arithmetic and no Jacobi smoother; its FMG start exists only as
+ * mg_dirichlet_analytic.c:771-806 (commented copy mg_3d.h:1364-1404).  Semantics are defined by
+ * csrc/mg3d_f32.hip and restated in plain C by the test infrastructure: binary32 storage and grid arithmetic with the
+ * reference's association per operator, v' = v + omega*((1/6)(sum6 - h^2 d) - v) out of place, the reference's
+ * double LU factors on the coarsest level (rhs widened, solution rounded), norms accumulated in double.
+ * Fields and levels are numbered as above (MG3D_U/D/R, 0 = coarsest); host arrays are N^3 floats, k fastest. */
+typedef struct mg3d32_ctx mg3d32_ctx;
+int mg3d32_create(int coarse_pts, int num_levels, int smooth_iters, double omega, double grid_length,
+                  mg3d32_ctx **out);
+int mg3d32_destroy(mg3d32_ctx *ctx);
+int mg3d32_level_n(const mg3d32_ctx *ctx, int level);
+int mg3d32_upload(mg3d32_ctx *ctx, int field, int level, const float *host);
+int mg3d32_download(mg3d32_ctx *ctx, int field, int level, float *host);
+int mg3d32_zero(mg3d32_ctx *ctx, int field, int level);
+int mg3d32_sync(mg3d32_ctx *ctx);
+int mg3d32_fill_boundary(mg3d32_ctx *ctx, int field, int level);   /* BCFunc (mg_3d.h:89) on the six faces */
+int mg3d32_smooth(mg3d32_ctx *ctx, int level, int iters);          /* `iters` damped-Jacobi sweeps */
+int mg3d32_residual(mg3d32_ctx *ctx, int level, int store, double *norm); /* mg_3d.h:794-842 in binary32 */
+int mg3d32_restrict(mg3d32_ctx *ctx, int level);                   /* r(level) -> d(level-1), mg_3d.h:844-998 */
+int mg3d32_prolong(mg3d32_ctx *ctx, int level);                    /* u(level) += P u(level-1), mg_3d.h:1000-1145 */
+int mg3d32_coarse_solve(mg3d32_ctx *ctx);                          /* gauss_elim.h:31-60 through double */
+int mg3d32_vcycles(mg3d32_ctx *ctx, int count, double *norms);     /* mg_3d.h:1242-1362 with the Jacobi smoother */
+int mg3d32_fmg_initialize(mg3d32_ctx *ctx);                        /* F-cycle start, mg_dirichlet_analytic.c:771-806 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 dp = C.POINTER(C.c_double)
+fp = C.POINTER(C.c_float)
 
 MG3D_U, MG3D_D, MG3D_R = 0, 1, 2
 STAGES = 7
@@ -93,6 +94,22 @@ SIGNATURES = {
     "mg3d_l2norm_host": (C.c_double, [dp, C.c_long]),
     "mg3d_smooth_edges_host": (None, [dp, C.c_int]),
     "mg3d_write_vtk": (C.c_int, [C.c_char_p, dp, C.c_double, C.c_int]),
+    # single precision / damped Jacobi / F-cycle variant (parity unpinned)
+    "mg3d32_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
+    "mg3d32_destroy": (C.c_int, [C.c_void_p]),
+    "mg3d32_level_n": (C.c_int, [C.c_void_p, C.c_int]),
+    "mg3d32_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, fp]),
+    "mg3d32_download": (C.c_int, [C.c_void_p, C.c_int, C.c_int, fp]),
+    "mg3d32_zero": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mg3d32_sync": (C.c_int, [C.c_void_p]),
+    "mg3d32_fill_boundary": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mg3d32_smooth": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mg3d32_residual": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
+    "mg3d32_restrict": (C.c_int, [C.c_void_p, C.c_int]),
+    "mg3d32_prolong": (C.c_int, [C.c_void_p, C.c_int]),
+    "mg3d32_coarse_solve": (C.c_int, [C.c_void_p]),
+    "mg3d32_vcycles": (C.c_int, [C.c_void_p, C.c_int, dp]),
+    "mg3d32_fmg_initialize": (C.c_int, [C.c_void_p]),
 }
 
 
@@ -377,3 +394,89 @@ class DistSolver:
 
     def sync(self):
         check(self.L.mg3d_dist_sync(self._h))
+
+
+def PF(a):
+    if a is None:
+        return None
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"], "need contiguous float32"
+    return a.ctypes.data_as(fp)
+
+
+class Solver32:
+    """The single-precision / damped-Jacobi / F-cycle variant (BASELINE configs[4]; parity unpinned: semantics in
+    csrc/mg3d_f32.hip, restated in plain C by the test infrastructure).  Same field and level numbering as `Solver`."""
+
+    def __init__(self, coarse_pts, num_levels, smooth_iters, omega=6.0 / 7.0, grid_length=1.0):
+        self.L = lib()
+        self._h = C.c_void_p()
+        check(self.L.mg3d32_create(coarse_pts, num_levels, smooth_iters, omega, grid_length, C.byref(self._h)))
+        self.c, self.num_levels, self.nu, self.omega = coarse_pts, num_levels, smooth_iters, omega
+        self.N = (coarse_pts - 1) * (1 << (num_levels - 1)) + 1
+
+    def close(self):
+        if self._h:
+            self.L.mg3d32_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def level_n(self, level):
+        return self.L.mg3d32_level_n(self._h, level)
+
+    def upload(self, field, level, host):
+        n = self.level_n(level)
+        assert host.size == n ** 3
+        check(self.L.mg3d32_upload(self._h, field, level, PF(np.ascontiguousarray(host, dtype=np.float32))))
+
+    def download(self, field, level):
+        out = np.empty(self.level_n(level) ** 3, dtype=np.float32)
+        check(self.L.mg3d32_download(self._h, field, level, PF(out)))
+        return out
+
+    def zero(self, field, level):
+        check(self.L.mg3d32_zero(self._h, field, level))
+
+    def sync(self):
+        check(self.L.mg3d32_sync(self._h))
+
+    def fill_boundary(self, field, level):
+        check(self.L.mg3d32_fill_boundary(self._h, field, level))
+
+    def smooth(self, level, iters):
+        check(self.L.mg3d32_smooth(self._h, level, iters))
+
+    def residual(self, level, store=True, want_norm=True):
+        n = C.c_double(0)
+        check(self.L.mg3d32_residual(self._h, level, 1 if store else 0, C.byref(n) if want_norm else None))
+        return n.value
+
+    def restrict(self, level):
+        check(self.L.mg3d32_restrict(self._h, level))
+
+    def prolong(self, level):
+        check(self.L.mg3d32_prolong(self._h, level))
+
+    def coarse_solve(self):
+        check(self.L.mg3d32_coarse_solve(self._h))
+
+    def setup_test_problem(self, fmg=False):
+        """test_mg_3d.c:11-29: boundary values on the faces of the finest u and d; with fmg=True on the faces of d
+        on every level (the F-cycle start of mg_dirichlet_analytic.c:771-806 reads them), then that start."""
+        top = self.num_levels - 1
+        if fmg:
+            for l in range(self.num_levels):
+                self.fill_boundary(MG3D_D, l)
+            check(self.L.mg3d32_fmg_initialize(self._h))
+        else:
+            self.fill_boundary(MG3D_U, top)
+            self.fill_boundary(MG3D_D, top)
+
+    def vcycles(self, count):
+        norms = np.zeros(count)
+        check(self.L.mg3d32_vcycles(self._h, count, P(norms)))
+        return norms

@@ -1,0 +1,654 @@
+/*
+ * mg3d_f32.hip -- the single-precision / damped-Jacobi / F-cycle variant (BASELINE configs[4]).
+ *
+ * PARITY UNPINNED: the reference has no fp32 arithmetic, no Jacobi smoother and only a commented-out FMG
+ * start (mg_3d.h:1364-1404, mg_dirichlet_analytic.c:771-806).  What this variant computes is therefore
+ * defined here and restated in plain C by the test infrastructure, which the tests compare with
+ * bit for bit:
+ *   - storage and grid arithmetic in IEEE binary32, no contraction, the reference's association for the
+ *     seven-point sum (mg_3d.h:438-443), the residual (:819-821), the 27-point restriction (:973-989) and
+ *     the parent orders of the prolongation (:1028-1138);
+ *   - smoother: weighted Jacobi, v' = v + omega * ((1/6) * (sum6 - h^2 d) - v), out of place;
+ *   - coarsest level: the reference's LU factors (double), the right-hand side widened, the solution
+ *     rounded back;
+ *   - norms: squares of the binary32 residuals accumulated in double;
+ *   - F-cycle: the FMG start of mg_dirichlet_analytic.c:771-806 (coarsest solve with boundary values, then per
+ *     level: prolongate the solution, re-impose the boundary values, zero the coarse guess, one V-cycle).
+ * First correct path: one launch per sweep (2 reads + 1 write per point and sweep), no temporal blocking.
+ */
+#include "mg3d_ctx.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define fail mg3d_fail
+#define HIPCHK(call)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(MG3D_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                      \
+    } while (0)
+#define CHK(call)           \
+    do {                    \
+        int rc_ = (call);   \
+        if (rc_ != MG3D_OK) \
+            return rc_;     \
+    } while (0)
+
+struct Level32 {
+    Geom g; /* pitch and plane in floats */
+    double hd; /* spacing as the hierarchy defines it (double); h = (float)hd */
+    float h, hSq, invHsq;
+    size_t elems;
+    float *f[3]; /* u, d, r */
+    float *alt;  /* the smoother's second buffer */
+};
+
+struct mg3d32_ctx {
+    int c, L, iters;
+    float omega;
+    std::vector<Level32> lv;
+    mg3d_ctx *coarse64; /* one-level double context: LU factors and the direct solve */
+    hipStream_t stream;
+    double *partials, *sumsq, *h_sumsq;
+    int sumsq_slots;
+};
+
+static inline int pitch32(int nk) { return (nk + 31) & ~31; }
+
+__device__ __forceinline__ long long gidx32(const Geom &g, int i, int j, int k)
+{
+    return g.plane * i + (long long)g.pitch * j + k;
+}
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+/* sum of the six neighbours in the reference's order (mg_3d.h:438-443): ((((i- + i+) + j-) + j+) + k-) + k+ */
+__device__ __forceinline__ float sum6(float im, float ip, float jm, float jp, float km, float kp)
+{
+    float s = im + ip;
+    s = s + jm;
+    s = s + jp;
+    s = s + km;
+    s = s + kp;
+    return s;
+}
+
+/* One damped-Jacobi sweep, out of place.  A thread owns four consecutive k of one row and marches `chunk`
+ * planes along i with its column's i-1 / i / i+1 values in registers; every point of the level is written
+ * (boundary points are copied) so the two buffers can simply be exchanged. */
+__global__ void __launch_bounds__(256) jacobi32_kernel(Geom g, const float *__restrict__ vin,
+                                                       const float *__restrict__ d, float *__restrict__ vout,
+                                                       float hSq, float sixth, float omega, int chunk)
+{
+    const int k0 = 4 * (blockIdx.x * 64 + threadIdx.x);
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    if (k0 >= g.nk || j >= g.nj)
+        return;
+    const int i0 = blockIdx.z * chunk, i1 = min(i0 + chunk, g.ni);
+    const bool jin = j >= 1 && j <= g.nj - 2;
+    long long p = gidx32(g, i0, j, k0);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 below = i0 > 0 ? ld4(vin + p - g.plane) : zero, here = ld4(vin + p);
+    for (int i = i0; i < i1; i++, p += g.plane) {
+        const float4 above = i + 1 < g.ni ? ld4(vin + p + g.plane) : zero;
+        float4 out = here;
+        if (jin && i >= 1 && i <= g.ni - 2) {
+            const float4 jm = ld4(vin + p - g.pitch), jp = ld4(vin + p + g.pitch), dd = ld4(d + p);
+            const float left = k0 > 0 ? vin[p - 1] : 0.f;
+            const float right = k0 + 4 < g.nk ? vin[p + 4] : 0.f;
+            const float hv[6] = {left, here.x, here.y, here.z, here.w, right};
+            const float bl[4] = {below.x, below.y, below.z, below.w}, ab[4] = {above.x, above.y, above.z, above.w};
+            const float jmv[4] = {jm.x, jm.y, jm.z, jm.w}, jpv[4] = {jp.x, jp.y, jp.z, jp.w};
+            const float dv[4] = {dd.x, dd.y, dd.z, dd.w};
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int k = k0 + c;
+                const float s = sum6(bl[c], ab[c], jmv[c], jpv[c], hv[c], hv[c + 2]) - hSq * dv[c];
+                const float gs = sixth * s;
+                o[c] = (k >= 1 && k <= g.nk - 2) ? hv[c + 1] + omega * (gs - hv[c + 1]) : hv[c + 1];
+            }
+            out = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        st4(vout + p, out);
+        below = here;
+        here = above;
+    }
+}
+
+__device__ __forceinline__ double wave_sum32(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        x += __shfl_down(x, off, 64);
+    return x;
+}
+
+/* diff = d - invHsq * (sum6 - 6 v) (mg_3d.h:819-821) in binary32; res (optional) on the interior only;
+ * per-block partial sums of (double)diff^2 in a fixed order */
+__global__ void __launch_bounds__(256) residual32_kernel(Geom g, const float *__restrict__ v,
+                                                         const float *__restrict__ d, float invHsq,
+                                                         float *__restrict__ res, double *__restrict__ partials,
+                                                         int chunk)
+{
+    __shared__ double lds4[4];
+    const int k0 = 4 * (blockIdx.x * 64 + threadIdx.x);
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    const int i0 = 1 + blockIdx.z * chunk, i1 = min(i0 + chunk, g.ni - 1);
+    double acc = 0.;
+    if (k0 < g.nk && j >= 1 && j <= g.nj - 2) {
+        long long p = gidx32(g, i0, j, k0);
+        float4 below = ld4(v + p - g.plane), here = ld4(v + p);
+        for (int i = i0; i < i1; i++, p += g.plane) {
+            const float4 above = ld4(v + p + g.plane);
+            const float4 jm = ld4(v + p - g.pitch), jp = ld4(v + p + g.pitch), dd = ld4(d + p);
+            const float left = k0 > 0 ? v[p - 1] : 0.f;
+            const float right = k0 + 4 < g.nk ? v[p + 4] : 0.f;
+            const float hv[6] = {left, here.x, here.y, here.z, here.w, right};
+            const float bl[4] = {below.x, below.y, below.z, below.w}, ab[4] = {above.x, above.y, above.z, above.w};
+            const float jmv[4] = {jm.x, jm.y, jm.z, jm.w}, jpv[4] = {jp.x, jp.y, jp.z, jp.w};
+            const float dv[4] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int k = k0 + c;
+                if (k >= 1 && k <= g.nk - 2) {
+                    const float s = sum6(bl[c], ab[c], jmv[c], jpv[c], hv[c], hv[c + 2]) - 6 * hv[c + 1];
+                    const float diff = dv[c] - invHsq * s;
+                    if (res)
+                        res[p + c] = diff;
+                    acc += (double)diff * (double)diff;
+                }
+            }
+            below = here;
+            here = above;
+        }
+    }
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    acc = wave_sum32(acc);
+    if ((tid & 63) == 0)
+        lds4[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0)
+        partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
+}
+
+/* restrictResidual (mg_3d.h:844-998) in binary32: faces by injection, interior by the 27-point sum in
+ * ti, tj, tk order starting from 0 */
+__global__ void __launch_bounds__(256) restrict32_kernel(Geom gf, const float *__restrict__ r, Geom gc,
+                                                         float *__restrict__ dc)
+{
+    const int kc = blockIdx.x * 64 + threadIdx.x, jc = blockIdx.y * 4 + threadIdx.y, ic = blockIdx.z;
+    if (kc >= gc.nk || jc >= gc.nj)
+        return;
+    const long long pf = gidx32(gf, 2 * ic, 2 * jc, 2 * kc);
+    const bool face = ic == 0 || ic == gc.ni - 1 || jc == 0 || jc == gc.nj - 1 || kc == 0 || kc == gc.nk - 1;
+    float val;
+    if (face) {
+        val = r[pf];
+    } else {
+        val = 0.f;
+#pragma unroll
+        for (int ti = -1; ti <= 1; ti++)
+#pragma unroll
+            for (int tj = -1; tj <= 1; tj++)
+#pragma unroll
+                for (int tk = -1; tk <= 1; tk++) {
+                    const float w = (ti ? 0.25f : 0.5f) * (tj ? 0.25f : 0.5f) * (tk ? 0.25f : 0.5f);
+                    val += r[pf + ti * gf.plane + tj * (long long)gf.pitch + tk] * w;
+                }
+    }
+    dc[gidx32(gc, ic, jc, kc)] = val;
+}
+
+/* prolongateAndCorrectError (mg_3d.h:1000-1145) in binary32, cell form: a thread owns the 2 x 2 fine points
+ * above one coarse cell and marches along i; parents summed in the reference's order per parity class */
+__global__ void __launch_bounds__(256) prolong32_kernel(Geom gc, const float *__restrict__ ec, Geom gf,
+                                                        float *__restrict__ ef, int chunk)
+{
+    const int m = blockIdx.x * 64 + threadIdx.x, jc = blockIdx.y * 4 + threadIdx.y;
+    const int k0 = 2 * m, j0 = 2 * jc;
+    if (k0 >= gf.nk || j0 >= gf.nj)
+        return;
+    const int i_beg = blockIdx.z * chunk, i_end = min(gf.ni, i_beg + chunk);
+    const bool row1 = j0 + 1 < gf.nj, col1 = k0 + 1 < gf.nk;
+    const int m1 = min(m + 1, gc.nk - 1), jc1 = min(jc + 1, gc.nj - 1);
+    const long long c00 = (long long)gc.pitch * jc + m, c01 = (long long)gc.pitch * jc + m1;
+    const long long c10 = (long long)gc.pitch * jc1 + m, c11 = (long long)gc.pitch * jc1 + m1;
+    float E0[2][2], E1[2][2];
+    int have = -0x40000000;
+    auto load = [&](int il, float(&E)[2][2]) {
+        const float *pl = ec + gc.plane * min(max(il, 0), gc.ni - 1);
+        E[0][0] = pl[c00];
+        E[0][1] = pl[c01];
+        E[1][0] = pl[c10];
+        E[1][1] = pl[c11];
+    };
+    for (int i = i_beg; i < i_end; i++) {
+        const int oi = i & 1, il = (i - oi) / 2;
+        if (have != il) {
+            if (have + 1 == il) {
+                E0[0][0] = E1[0][0];
+                E0[0][1] = E1[0][1];
+                E0[1][0] = E1[1][0];
+                E0[1][1] = E1[1][1];
+            } else {
+                load(il, E0);
+            }
+            load(il + 1, E1);
+            have = il;
+        }
+        float t00, t01, t10, t11;
+        if (!oi) {
+            t00 = E0[0][0];
+            t01 = (E0[0][0] + E0[0][1]) * 0.5f;
+            t10 = (E0[0][0] + E0[1][0]) * 0.5f;
+            t11 = (((E0[0][0] + E0[1][0]) + E0[0][1]) + E0[1][1]) * 0.25f;
+        } else {
+            t00 = (E0[0][0] + E1[0][0]) * 0.5f;
+            t01 = (((E0[0][0] + E1[0][0]) + E0[0][1]) + E1[0][1]) * 0.25f;
+            t10 = (((E0[0][0] + E0[1][0]) + E1[0][0]) + E1[1][0]) * 0.25f;
+            float t = E0[0][0] + E0[0][1];
+            t = t + E0[1][0];
+            t = t + E0[1][1];
+            t = t + E1[0][0];
+            t = t + E1[0][1];
+            t = t + E1[1][0];
+            t = t + E1[1][1];
+            t11 = t * 0.125f;
+        }
+        float *row = ef + gf.plane * i + (long long)gf.pitch * j0 + k0;
+        float2 a = *reinterpret_cast<float2 *>(row);
+        a.x += t00;
+        if (col1)
+            a.y += t01;
+        *reinterpret_cast<float2 *>(row) = a;
+        if (row1) {
+            float2 b = *reinterpret_cast<float2 *>(row + gf.pitch);
+            b.x += t10;
+            if (col1)
+                b.y += t11;
+            *reinterpret_cast<float2 *>(row + gf.pitch) = b;
+        }
+    }
+}
+
+/* boundary values x^2 - 2y^2 + z^2 (mg_3d.h:89-90) evaluated in double at (i h, j h, k h) and rounded once */
+__global__ void __launch_bounds__(256) fill_boundary32_kernel(Geom g, float *__restrict__ v, double h)
+{
+    const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
+    if (k >= g.nk || j >= g.nj)
+        return;
+    if (!(i == 0 || i == g.ni - 1 || j == 0 || j == g.nj - 1 || k == 0 || k == g.nk - 1))
+        return;
+    const double x = i * h, y = j * h, z = k * h;
+    v[gidx32(g, i, j, k)] = (float)(x * x - 2 * y * y + z * z);
+}
+
+/* coarsest level <-> the double context of the direct solve */
+__global__ void widen32_kernel(Geom g32, const float *__restrict__ a, Geom g64, double *__restrict__ b)
+{
+    const int k = threadIdx.x, j = blockIdx.x, i = blockIdx.y;
+    if (k < g32.nk)
+        b[g64.plane * i + (long long)g64.pitch * j + k] = (double)a[gidx32(g32, i, j, k)];
+}
+__global__ void narrow32_kernel(Geom g64, const double *__restrict__ a, Geom g32, float *__restrict__ b)
+{
+    const int k = threadIdx.x, j = blockIdx.x, i = blockIdx.y;
+    if (k < g32.nk)
+        b[gidx32(g32, i, j, k)] = (float)a[g64.plane * i + (long long)g64.pitch * j + k];
+}
+
+/* ------------------------------------------------------------------------------------------ context */
+extern "C" int mg3d32_destroy(mg3d32_ctx *ctx)
+{
+    if (!ctx)
+        return MG3D_OK;
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    for (auto &l : ctx->lv) {
+        for (int k = 0; k < 3; k++)
+            if (l.f[k])
+                (void)hipFree(l.f[k]);
+        if (l.alt)
+            (void)hipFree(l.alt);
+    }
+    if (ctx->partials)
+        (void)hipFree(ctx->partials);
+    if (ctx->sumsq)
+        (void)hipFree(ctx->sumsq);
+    if (ctx->h_sumsq)
+        (void)hipHostFree(ctx->h_sumsq);
+    if (ctx->coarse64)
+        mg3d_ctx_destroy(ctx->coarse64); /* owns the stream */
+    delete ctx;
+    return MG3D_OK;
+}
+
+extern "C" int mg3d32_create(int coarse_pts, int num_levels, int smooth_iters, double omega, double grid_length,
+                             mg3d32_ctx **out)
+{
+    if (!out || coarse_pts < 3 || coarse_pts > 11 || num_levels < 1 || num_levels > 24 || smooth_iters < 0 ||
+        !(omega > 0.) || !(grid_length > 0.))
+        return fail(MG3D_ERR_ARG, "mg3d32_create: bad arguments");
+    if (mg3d_device_count() <= 0)
+        return fail(MG3D_ERR_NO_DEVICE, "no HIP device available: libmg3d has no CPU fallback");
+    mg3d32_ctx *ctx = new mg3d32_ctx();
+    ctx->c = coarse_pts;
+    ctx->L = num_levels;
+    ctx->iters = smooth_iters;
+    ctx->omega = (float)omega;
+    ctx->coarse64 = nullptr;
+    ctx->partials = ctx->sumsq = ctx->h_sumsq = nullptr;
+    ctx->stream = nullptr;
+    int rc = mg3d_ctx_create(coarse_pts, 1, smooth_iters, 1.0, &ctx->coarse64);
+    if (rc != MG3D_OK) {
+        delete ctx;
+        return rc;
+    }
+    ctx->stream = ctx->coarse64->stream;
+    const long long finest = ((long long)(coarse_pts - 1) << (num_levels - 1)) + 1;
+    std::vector<double> hs(num_levels);
+    hs[num_levels - 1] = grid_length / (double)(finest - 1);
+    for (int l = num_levels - 2; l >= 0; l--)
+        hs[l] = 2 * hs[l + 1];
+    /* the coarse operator is the reference's, with the coarsest spacing (mg_3d.h:287) */
+    rc = mg3d_ctx_build_coarse(ctx->coarse64, hs[0]);
+    if (rc != MG3D_OK) {
+        mg3d32_destroy(ctx);
+        return rc;
+    }
+#define C32(call)                                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            const int rc_ = fail(e_ == hipErrorOutOfMemory ? MG3D_ERR_ALLOC : MG3D_ERR_HIP,   \
+                                 "%s failed: %s", #call, hipGetErrorString(e_));               \
+            mg3d32_destroy(ctx);                                                               \
+            return rc_;                                                                        \
+        }                                                                                      \
+    } while (0)
+    ctx->lv.resize(num_levels);
+    for (int l = 0; l < num_levels; l++) {
+        Level32 &lev = ctx->lv[l];
+        const int N = (coarse_pts - 1) * (1 << l) + 1;
+        lev.g.ni = lev.g.nj = lev.g.nk = lev.g.N = N;
+        lev.g.ig0 = 0;
+        lev.g.pitch = pitch32(N);
+        lev.g.plane = (long long)lev.g.pitch * N;
+        lev.hd = hs[l];
+        lev.h = (float)hs[l];
+        lev.hSq = lev.h * lev.h;
+        lev.invHsq = 1.0f / (lev.h * lev.h);
+        lev.elems = (size_t)lev.g.plane * N;
+        for (int k = 0; k < 3; k++)
+            lev.f[k] = nullptr;
+        lev.alt = nullptr;
+    }
+    for (auto &lev : ctx->lv) {
+        for (int k = 0; k < 3; k++) {
+            C32(hipMalloc(&lev.f[k], lev.elems * sizeof(float)));
+            C32(hipMemsetAsync(lev.f[k], 0, lev.elems * sizeof(float), ctx->stream));
+        }
+        C32(hipMalloc(&lev.alt, lev.elems * sizeof(float)));
+        C32(hipMemsetAsync(lev.alt, 0, lev.elems * sizeof(float), ctx->stream));
+    }
+    ctx->sumsq_slots = 1024;
+    C32(hipMalloc(&ctx->partials, sizeof(double) * MG3D_MAX_PARTIALS));
+    C32(hipMalloc(&ctx->sumsq, sizeof(double) * ctx->sumsq_slots));
+    C32(hipHostMalloc(&ctx->h_sumsq, sizeof(double) * ctx->sumsq_slots));
+    C32(hipStreamSynchronize(ctx->stream));
+#undef C32
+    *out = ctx;
+    return MG3D_OK;
+}
+
+extern "C" int mg3d32_level_n(const mg3d32_ctx *ctx, int level)
+{
+    return (ctx && level >= 0 && level < ctx->L) ? ctx->lv[level].g.N : -1;
+}
+
+static int check32(mg3d32_ctx *ctx, int field, int level, const char *who)
+{
+    if (!ctx || field < 0 || field > 2 || level < 0 || level >= ctx->L)
+        return fail(MG3D_ERR_ARG, "%s: bad field/level", who);
+    return MG3D_OK;
+}
+
+extern "C" int mg3d32_upload(mg3d32_ctx *ctx, int field, int level, const float *host)
+{
+    CHK(check32(ctx, field, level, "mg3d32_upload"));
+    Level32 &l = ctx->lv[level];
+    const int N = l.g.N;
+    HIPCHK(hipMemcpy2DAsync(l.f[field], l.g.pitch * sizeof(float), host, N * sizeof(float), N * sizeof(float),
+                            (size_t)N * N, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MG3D_OK;
+}
+
+extern "C" int mg3d32_download(mg3d32_ctx *ctx, int field, int level, float *host)
+{
+    CHK(check32(ctx, field, level, "mg3d32_download"));
+    Level32 &l = ctx->lv[level];
+    const int N = l.g.N;
+    HIPCHK(hipMemcpy2DAsync(host, N * sizeof(float), l.f[field], l.g.pitch * sizeof(float), N * sizeof(float),
+                            (size_t)N * N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MG3D_OK;
+}
+
+extern "C" int mg3d32_sync(mg3d32_ctx *ctx)
+{
+    if (!ctx)
+        return fail(MG3D_ERR_ARG, "mg3d32_sync: NULL");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MG3D_OK;
+}
+
+/* ---------------------------------------------------------------------------------------- operators */
+static int chunk_for(int planes, long long blocks_per_plane, long long want = 4096)
+{
+    int chunk = 64;
+    while (chunk > 4 && blocks_per_plane * ((planes + chunk - 1) / chunk) < want)
+        chunk /= 2;
+    return chunk;
+}
+
+static void e_jacobi(mg3d32_ctx *ctx, int level, int iters)
+{
+    Level32 &l = ctx->lv[level];
+    const int gx = ((l.g.nk + 3) / 4 + 63) / 64, gy = (l.g.nj + 3) / 4;
+    const int chunk = chunk_for(l.g.ni, (long long)gx * gy);
+    for (int it = 0; it < iters; it++) {
+        hipLaunchKernelGGL(jacobi32_kernel, dim3(gx, gy, (l.g.ni + chunk - 1) / chunk), dim3(64, 4, 1), 0, ctx->stream,
+                           l.g, l.f[MG3D_U], l.f[MG3D_D], l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, chunk);
+        float *t = l.f[MG3D_U];
+        l.f[MG3D_U] = l.alt;
+        l.alt = t;
+    }
+}
+
+static void e_residual(mg3d32_ctx *ctx, int level, bool store, int slot)
+{
+    Level32 &l = ctx->lv[level];
+    if (l.g.N < 3) {
+        (void)hipMemsetAsync(ctx->sumsq + slot, 0, sizeof(double), ctx->stream);
+        return;
+    }
+    const int gx = ((l.g.nk + 3) / 4 + 63) / 64, gy = (l.g.nj + 3) / 4;
+    int chunk = chunk_for(l.g.ni - 2, (long long)gx * gy);
+    while ((long long)gx * gy * ((l.g.ni - 2 + chunk - 1) / chunk) > MG3D_MAX_PARTIALS)
+        chunk *= 2;
+    const int gz = (l.g.ni - 2 + chunk - 1) / chunk;
+    hipLaunchKernelGGL(residual32_kernel, dim3(gx, gy, gz), dim3(64, 4, 1), 0, ctx->stream, l.g, l.f[MG3D_U],
+                       l.f[MG3D_D], l.invHsq, store ? l.f[MG3D_R] : nullptr, ctx->partials, chunk);
+    k_fold(ctx->partials, gx * gy * gz, ctx->sumsq + slot, ctx->stream);
+}
+
+static void e_restrict(mg3d32_ctx *ctx, int level)
+{
+    Level32 &lf = ctx->lv[level], &lc = ctx->lv[level - 1];
+    hipLaunchKernelGGL(restrict32_kernel, dim3((lc.g.nk + 63) / 64, (lc.g.nj + 3) / 4, lc.g.ni), dim3(64, 4, 1), 0,
+                       ctx->stream, lf.g, lf.f[MG3D_R], lc.g, lc.f[MG3D_D]);
+}
+
+static void e_prolong(mg3d32_ctx *ctx, int level)
+{
+    Level32 &lf = ctx->lv[level], &lc = ctx->lv[level - 1];
+    const int gx = ((lf.g.nk + 1) / 2 + 63) / 64, gy = ((lf.g.nj + 1) / 2 + 3) / 4;
+    const int chunk = chunk_for(lf.g.ni, (long long)gx * gy, 2048);
+    hipLaunchKernelGGL(prolong32_kernel, dim3(gx, gy, (lf.g.ni + chunk - 1) / chunk), dim3(64, 4, 1), 0, ctx->stream,
+                       lc.g, lc.f[MG3D_U], lf.g, lf.f[MG3D_U], chunk);
+}
+
+static int e_coarse_solve(mg3d32_ctx *ctx)
+{
+    Level32 &l0 = ctx->lv[0];
+    Level &c0 = ctx->coarse64->lv[0];
+    const dim3 grid(l0.g.nj, l0.g.ni);
+    hipLaunchKernelGGL(widen32_kernel, grid, dim3(64), 0, ctx->stream, l0.g, l0.f[MG3D_D], c0.g, c0.f[MG3D_D]);
+    CHK(mg3d_coarse_solve(ctx->coarse64));
+    hipLaunchKernelGGL(narrow32_kernel, grid, dim3(64), 0, ctx->stream, c0.g, c0.f[MG3D_U], l0.g, l0.f[MG3D_U]);
+    return MG3D_OK;
+}
+
+static void e_fill_boundary(mg3d32_ctx *ctx, int field, int level)
+{
+    Level32 &l = ctx->lv[level];
+    hipLaunchKernelGGL(fill_boundary32_kernel, dim3((l.g.nk + 63) / 64, (l.g.nj + 3) / 4, l.g.ni), dim3(64, 4, 1), 0,
+                       ctx->stream, l.g, l.f[field], l.hd);
+}
+
+static int launch_ok32(const char *who)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(MG3D_ERR_HIP, "%s: kernel launch failed: %s", who, hipGetErrorString(e));
+    return MG3D_OK;
+}
+
+/* the V-cycle of mg_3d.h:1242-1362 with the Jacobi smoother; the level's norm lands in sumsq[slot] */
+static int e_vcycle(mg3d32_ctx *ctx, int q, int slot)
+{
+    if (q == 0)
+        return e_coarse_solve(ctx);
+    e_jacobi(ctx, q, ctx->iters);                       /* :1282 */
+    e_residual(ctx, q, true, ctx->sumsq_slots - 1);     /* :1294 (its norm is dropped) */
+    e_restrict(ctx, q);                                 /* :1310 */
+    Level32 &lc = ctx->lv[q - 1];
+    (void)hipMemsetAsync(lc.f[MG3D_U], 0, lc.elems * sizeof(float), ctx->stream); /* :1258 */
+    CHK(e_vcycle(ctx, q - 1, ctx->sumsq_slots - 1));    /* :1321 */
+    e_prolong(ctx, q);                                  /* :1331 */
+    e_jacobi(ctx, q, ctx->iters);                       /* :1341 */
+    e_residual(ctx, q, false, slot);                    /* :1354 */
+    return MG3D_OK;
+}
+
+extern "C" int mg3d32_smooth(mg3d32_ctx *ctx, int level, int iters)
+{
+    CHK(check32(ctx, 0, level, "mg3d32_smooth"));
+    if (iters < 0)
+        return fail(MG3D_ERR_ARG, "mg3d32_smooth: negative sweep count");
+    if (ctx->lv[level].g.N >= 3)
+        e_jacobi(ctx, level, iters);
+    return launch_ok32("mg3d32_smooth");
+}
+
+static int norm_out(mg3d32_ctx *ctx, int slot, double *norm)
+{
+    if (norm) {
+        HIPCHK(hipMemcpyAsync(ctx->h_sumsq, ctx->sumsq + slot, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        *norm = sqrt(ctx->h_sumsq[0]);
+    }
+    return MG3D_OK;
+}
+
+extern "C" int mg3d32_residual(mg3d32_ctx *ctx, int level, int store, double *norm)
+{
+    CHK(check32(ctx, 0, level, "mg3d32_residual"));
+    e_residual(ctx, level, store != 0, 0);
+    CHK(launch_ok32("mg3d32_residual"));
+    return norm_out(ctx, 0, norm);
+}
+
+extern "C" int mg3d32_restrict(mg3d32_ctx *ctx, int level)
+{
+    CHK(check32(ctx, 0, level, "mg3d32_restrict"));
+    if (level < 1)
+        return fail(MG3D_ERR_ARG, "mg3d32_restrict: no coarser level");
+    e_restrict(ctx, level);
+    return launch_ok32("mg3d32_restrict");
+}
+
+extern "C" int mg3d32_prolong(mg3d32_ctx *ctx, int level)
+{
+    CHK(check32(ctx, 0, level, "mg3d32_prolong"));
+    if (level < 1)
+        return fail(MG3D_ERR_ARG, "mg3d32_prolong: no coarser level");
+    e_prolong(ctx, level);
+    return launch_ok32("mg3d32_prolong");
+}
+
+extern "C" int mg3d32_coarse_solve(mg3d32_ctx *ctx)
+{
+    if (!ctx)
+        return fail(MG3D_ERR_ARG, "mg3d32_coarse_solve: NULL");
+    CHK(e_coarse_solve(ctx));
+    return launch_ok32("mg3d32_coarse_solve");
+}
+
+extern "C" int mg3d32_fill_boundary(mg3d32_ctx *ctx, int field, int level)
+{
+    CHK(check32(ctx, field, level, "mg3d32_fill_boundary"));
+    e_fill_boundary(ctx, field, level);
+    return launch_ok32("mg3d32_fill_boundary");
+}
+
+extern "C" int mg3d32_zero(mg3d32_ctx *ctx, int field, int level)
+{
+    CHK(check32(ctx, field, level, "mg3d32_zero"));
+    HIPCHK(hipMemsetAsync(ctx->lv[level].f[field], 0, ctx->lv[level].elems * sizeof(float), ctx->stream));
+    return MG3D_OK;
+}
+
+/* `count` V-cycles from the finest level, device resident; norms[c] = ||d - A u|| after cycle c */
+extern "C" int mg3d32_vcycles(mg3d32_ctx *ctx, int count, double *norms)
+{
+    if (!ctx || count < 0)
+        return fail(MG3D_ERR_ARG, "mg3d32_vcycles: bad arguments");
+    const int slots = ctx->sumsq_slots - 1;
+    for (int done = 0; done < count;) {
+        const int nb = count - done < slots ? count - done : slots;
+        for (int c = 0; c < nb; c++)
+            CHK(e_vcycle(ctx, ctx->L - 1, c));
+        CHK(launch_ok32("mg3d32_vcycles"));
+        HIPCHK(hipMemcpyAsync(ctx->h_sumsq, ctx->sumsq, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (norms)
+            for (int c = 0; c < nb; c++)
+                norms[done + c] = sqrt(ctx->h_sumsq[c]);
+        done += nb;
+    }
+    return MG3D_OK;
+}
+
+/* F-cycle start (FMG), mg_dirichlet_analytic.c:771-806: the right-hand sides d of ALL levels are the caller's */
+extern "C" int mg3d32_fmg_initialize(mg3d32_ctx *ctx)
+{
+    if (!ctx)
+        return fail(MG3D_ERR_ARG, "mg3d32_fmg_initialize: NULL");
+    e_fill_boundary(ctx, MG3D_U, 0);     /* :780 */
+    CHK(e_coarse_solve(ctx));            /* :783 */
+    for (int l = 1; l < ctx->L; l++) {
+        e_prolong(ctx, l);               /* :795 */
+        e_fill_boundary(ctx, MG3D_U, l); /* :798 */
+        Level32 &lc = ctx->lv[l - 1];
+        HIPCHK(hipMemsetAsync(lc.f[MG3D_U], 0, lc.elems * sizeof(float), ctx->stream)); /* :801 */
+        CHK(e_vcycle(ctx, l, ctx->sumsq_slots - 1));                                    /* :804 */
+    }
+    return launch_ok32("mg3d32_fmg_initialize");
+}

@@ -85,4 +85,19 @@ void orc_set_threads(int n);
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- single precision / damped Jacobi / F-cycle variant (mg3d_oracle_f32.c; PARITY UNPINNED, see its header) */
+void orc32_fill_boundary(float *v, int N, double h);
+void orc32_jacobi(const float *vin, const float *d, float *vout, int N, float h, float omega);
+void orc32_smooth(float *v, const float *d, float *scratch, int N, float h, float omega, int iters);
+double orc32_residual(const float *v, const float *d, int N, float h, float *res);
+void orc32_restrict(const float *r, int Nf, float *dc, int Nc);
+void orc32_prolong(const float *ec, int Nc, float *ef, int Nf);
+void orc32_coarse_solve(const double *LU, int n, const float *b, float *x);
+double orc32_vcycle(float **u, float **d, float **r, float **scratch, double hd, int q, int iters, float omega, int N,
+                    const double *LU);
+void orc32_fmg_initialize(float **u, float **d, float **r, float **scratch, int c, int numLevels, int iters,
+                          float omega, double grid_length, const double *LU);
+double orc32_run_problem(int c, int L, int iters, double omega, int cycles, int use_fmg, double *norms, float *u_out);
+
 #endif

@@ -7,11 +7,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 dp = C.POINTER(C.c_double)
+fp = C.POINTER(C.c_float)
 
 
 def P(a):
     assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(dp)
+
+
+def PF(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(fp)
 
 
 _lib = None
@@ -41,6 +47,17 @@ def lib():
         L.orc_fmg_initialize.argtypes = [C.POINTER(dp)] * 3 + [C.c_int, C.c_int, C.c_int, C.c_double, dp]
         L.orc_run_problem.restype = C.c_double
         L.orc_run_problem.argtypes = [C.c_int] * 5 + [dp, dp, dp]
+        # single precision / Jacobi / F-cycle variant (oracle/mg3d_oracle_f32.c, parity unpinned)
+        L.orc32_fill_boundary.argtypes = [fp, C.c_int, C.c_double]
+        L.orc32_jacobi.argtypes = [fp, fp, fp, C.c_int, C.c_float, C.c_float]
+        L.orc32_smooth.argtypes = [fp, fp, fp, C.c_int, C.c_float, C.c_float, C.c_int]
+        L.orc32_residual.restype = C.c_double
+        L.orc32_residual.argtypes = [fp, fp, C.c_int, C.c_float, fp]
+        L.orc32_restrict.argtypes = [fp, C.c_int, fp, C.c_int]
+        L.orc32_prolong.argtypes = [fp, C.c_int, fp, C.c_int]
+        L.orc32_coarse_solve.argtypes = [dp, C.c_int, fp, fp]
+        L.orc32_run_problem.restype = C.c_double
+        L.orc32_run_problem.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, dp, fp]
         L.orc_max_threads.restype = C.c_int
         L.orc_set_threads.argtypes = [C.c_int]
         _lib = L

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "mg3d.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mg3d_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(mg3d(?:32)?_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_every_declared_symbol_is_exported_and_bound():

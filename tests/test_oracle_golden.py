@@ -178,3 +178,45 @@ def test_fmg_initialize_bit_exact(c, L, nu):
     norms = [O.lib().orc_vcycle(H.ptrs(H.u), H.ptrs(H.d), H.ptrs(H.r), h, L - 1, L, nu, N, O.P(LU)) for _ in range(3)]
     assert np.array_equal(np.array(norms), V[f"norms_{key}"])
     assert np.array_equal(H.u[-1], V[f"u_{key}"])
+
+
+def test_f32_restatement_is_consistent_with_the_pinned_double_oracle():
+    """oracle/mg3d_oracle_f32.c is parity-unpinned (no reference implementation of fp32 / Jacobi / F-cycle).  What
+    can be checked on the CPU: with omega = 1 and one sweep its Jacobi update is the binary32 rounding of the
+    double seven-point average; its transfer operators are the binary32 versions of the pinned double ones; its
+    F-cycle + V-cycles reach the double solution to binary32 accuracy."""
+    import ctypes as C
+    lib = O.lib()
+    N, Nc = 9, 5
+    rng = np.random.default_rng(3)
+    u64, d64 = rng.uniform(-1, 1, N ** 3), rng.uniform(-1, 1, N ** 3)
+    u32, d32 = u64.astype(np.float32), d64.astype(np.float32)
+    h = 1.0 / (N - 1)
+    out = np.zeros_like(u32)
+    lib.orc32_jacobi(O.PF(u32), O.PF(d32), O.PF(out), N, C.c_float(h), C.c_float(1.0))
+    U = u32.astype(np.float64).reshape(N, N, N)
+    D = d32.astype(np.float64).reshape(N, N, N)
+    avg = (U[:-2, 1:-1, 1:-1] + U[2:, 1:-1, 1:-1] + U[1:-1, :-2, 1:-1] + U[1:-1, 2:, 1:-1] + U[1:-1, 1:-1, :-2]
+           + U[1:-1, 1:-1, 2:] - h * h * D[1:-1, 1:-1, 1:-1]) / 6
+    got = out.reshape(N, N, N)
+    assert np.abs(got[1:-1, 1:-1, 1:-1] - avg).max() < 4e-7
+    assert np.array_equal(got[0], u32.reshape(N, N, N)[0])  # boundary copied
+    # restriction / prolongation against the double oracle on binary32-representable data
+    r64 = u32.astype(np.float64)
+    dc64, dc32 = np.zeros(Nc ** 3), np.zeros(Nc ** 3, dtype=np.float32)
+    lib.orc_restrict(O.P(r64), N, O.P(dc64), Nc)
+    lib.orc32_restrict(O.PF(u32), N, O.PF(dc32), Nc)
+    assert np.abs(dc32 - dc64).max() < 1e-6
+    ef64, ef32 = d32.astype(np.float64), d32.copy()
+    ec32 = rng.uniform(-1, 1, Nc ** 3).astype(np.float32)
+    lib.orc_prolong(O.P(ec32.astype(np.float64)), Nc, O.P(ef64), N)
+    lib.orc32_prolong(O.PF(ec32), Nc, O.PF(ef32), N)
+    assert np.abs(ef32 - ef64).max() < 1e-6
+    # whole solve: 33^3, F-cycle start + 12 V(2,2) cycles with omega = 6/7
+    c, L = 5, 4
+    Nf = 33
+    norms, uf = np.zeros(12), np.zeros(Nf ** 3, dtype=np.float32)
+    lib.orc32_run_problem(c, L, 2, 6.0 / 7.0, 12, 1, O.P(norms), O.PF(uf))
+    _, u_ref, _, _ = O.run_problem(c, L, 2, 12)
+    assert np.abs(uf - u_ref).max() < 1e-4
+    assert norms[-1] < 1.0
