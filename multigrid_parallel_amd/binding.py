@@ -468,6 +468,9 @@ class Solver32:
         """test_mg_3d.c:11-29: boundary values on the faces of the finest u and d; with fmg=True on the faces of d
         on every level (the F-cycle start of mg_dirichlet_analytic.c:771-806 reads them), then that start."""
         top = self.num_levels - 1
+        for l in range(self.num_levels):  # a clean hierarchy, as after the reference's calloc (mg_3d.h:44)
+            for f in (MG3D_U, MG3D_D, MG3D_R):
+                self.zero(f, l)
         if fmg:
             for l in range(self.num_levels):
                 self.fill_boundary(MG3D_D, l)

@@ -152,15 +152,23 @@ __global__ void __launch_bounds__(256) residual32_kernel(Geom g, const float *__
             const float bl[4] = {below.x, below.y, below.z, below.w}, ab[4] = {above.x, above.y, above.z, above.w};
             const float jmv[4] = {jm.x, jm.y, jm.z, jm.w}, jpv[4] = {jp.x, jp.y, jp.z, jp.w};
             const float dv[4] = {dd.x, dd.y, dd.z, dd.w};
+            float df[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int k = k0 + c;
-                if (k >= 1 && k <= g.nk - 2) {
-                    const float s = sum6(bl[c], ab[c], jmv[c], jpv[c], hv[c], hv[c + 2]) - 6 * hv[c + 1];
-                    const float diff = dv[c] - invHsq * s;
-                    if (res)
-                        res[p + c] = diff;
-                    acc += (double)diff * (double)diff;
+                const float s = sum6(bl[c], ab[c], jmv[c], jpv[c], hv[c], hv[c + 2]) - 6 * hv[c + 1];
+                df[c] = dv[c] - invHsq * s;
+                if (k >= 1 && k <= g.nk - 2)
+                    acc += (double)df[c] * (double)df[c];
+            }
+            if (res) { /* interior only (mg_3d.h:824-825): one 16-byte store unless the vector touches a face */
+                if (k0 >= 1 && k0 + 3 <= g.nk - 2) {
+                    st4(res + p, make_float4(df[0], df[1], df[2], df[3]));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        if (k0 + c >= 1 && k0 + c <= g.nk - 2)
+                            res[p + c] = df[c];
                 }
             }
             below = here;
