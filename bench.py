@@ -202,7 +202,12 @@ def main():
                 "vcycle_algorithmic_gb": alg / 1e9, "vcycle_algorithmic_gbs": alg / per_step / 1e9,
                 "vcycle_frac_of_hbm_peak": alg / per_step / 1e9 / (HBM_PEAK_GBS * world),
                 "first_norm": float(norms[0]), "last_norm": float(norms[-1]), "initial_rhs_norm": init,
-                "roofline": None, "cpu_baseline": None}))
+                # no per-kernel timers on the slab path: the whole cycle against the aggregate HBM peak (the
+                # per-kernel roofline and the CPU baseline belong to the N = 1 line)
+                "roofline": {"bound": "hbm", "kernel": "whole V-cycle, all ranks (algorithmic bytes of SURVEY 8(d))",
+                             "achieved": alg / per_step / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                             "frac": alg / per_step / 1e9 / (HBM_PEAK_GBS * world), "traffic": None},
+                "cpu_baseline": None}))
         solver.close()
         dist.destroy_process_group()
         return
