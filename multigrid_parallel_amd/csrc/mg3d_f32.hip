@@ -120,6 +120,87 @@ __global__ void __launch_bounds__(256) jacobi32_kernel(Geom g, const float *__re
     }
 }
 
+/* Two damped-Jacobi sweeps in one pass over the level (temporal blocking through LDS).
+ * A 1024-thread block owns an extended tile of 16 rows x 256 columns (one wave per row, four k per lane) and
+ * marches along i.  With input planes a-2, a-1, a of its column in registers a thread forms sweep 1 of plane
+ * a-1 (row and column neighbours of that plane from LDS / the neighbouring lanes), then -- with sweep-1 planes
+ * a-3, a-2, a-1 in registers -- sweep 2 of plane a-2.  The outermost ring of the tile is valid input only, the
+ * next ring valid after sweep 1 only: 12 x 248 points per plane leave the block (1.38x redundant reads instead
+ * of a second pass over HBM).  Input and sweep-1 planes are double-buffered in LDS: one barrier per plane. */
+__device__ __forceinline__ float4 jacobi_pt4(float4 below, float4 above, float4 jm, float4 jp, float left, float4 here,
+                                             float right, float4 dd, float hSq, float sixth, float omega, bool upd_plane_row,
+                                             int k0, int nk)
+{
+    const float hv[6] = {left, here.x, here.y, here.z, here.w, right};
+    const float bl[4] = {below.x, below.y, below.z, below.w}, ab[4] = {above.x, above.y, above.z, above.w};
+    const float jmv[4] = {jm.x, jm.y, jm.z, jm.w}, jpv[4] = {jp.x, jp.y, jp.z, jp.w};
+    const float dv[4] = {dd.x, dd.y, dd.z, dd.w};
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int k = k0 + c;
+        const float s = sum6(bl[c], ab[c], jmv[c], jpv[c], hv[c], hv[c + 2]) - hSq * dv[c];
+        const float gs = sixth * s;
+        o[c] = (upd_plane_row && k >= 1 && k <= nk - 2) ? hv[c + 1] + omega * (gs - hv[c + 1]) : hv[c + 1];
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+constexpr int J2_ROWS = 16, J2_OUT_ROWS = 12, J2_OUT_COLS = 248;
+
+__global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *__restrict__ vin,
+                                                          const float *__restrict__ d, float *__restrict__ vout,
+                                                          float hSq, float sixth, float omega, int chunk)
+{
+    __shared__ float4 inp[2][J2_ROWS][64];
+    __shared__ float4 s1b[2][J2_ROWS][64];
+    const int lane = threadIdx.x, r = threadIdx.y;
+    const int j = (int)blockIdx.y * J2_OUT_ROWS - 2 + r;
+    const int k0 = (int)blockIdx.x * J2_OUT_COLS - 4 + 4 * lane;
+    const int i0 = blockIdx.z * chunk, i1 = min(i0 + chunk, g.ni);
+    const bool in_dom = j >= 0 && j < g.nj && k0 >= 0 && k0 < g.nk; /* pitch covers a partial last vector */
+    const bool row_upd = j >= 1 && j <= g.nj - 2;
+    const bool own = in_dom && r >= 2 && r < 2 + J2_OUT_ROWS && lane >= 1 && lane <= 62;
+    const long long col = (long long)g.pitch * j + k0;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load = [&](const float *base, int i) { return (in_dom && i >= 0 && i < g.ni) ? ld4(base + g.plane * i + col) : zero; };
+    const int rm = r > 0 ? r - 1 : r, rp = r < J2_ROWS - 1 ? r + 1 : r;
+    /* registers: input planes a-2 (in_m), a-1 (in_c); sweep-1 planes a-3 (s_m), a-2 (s_c); d of plane a-2 */
+    float4 in_m = load(vin, i0 - 3), in_c = load(vin, i0 - 2), s_m = zero, s_c = zero, d2 = zero;
+    for (int a = i0 - 1; a <= i1 + 1; a++) {
+        const float4 in_p = load(vin, a);
+        const float4 d1 = load(d, a - 1);
+        const int pb = a & 1;
+        inp[pb][r][lane] = in_c;
+        __syncthreads();
+        /* sweep 1 of plane a-1 */
+        float4 s_new;
+        {
+            const float4 jm = inp[pb][rm][lane], jp = inp[pb][rp][lane];
+            const float left = __shfl_up(in_c.w, 1, 64), right = __shfl_down(in_c.x, 1, 64);
+            const int q = a - 1;
+            s_new = jacobi_pt4(in_m, in_p, jm, jp, left, in_c, right, d1, hSq, sixth, omega,
+                               row_upd && q >= 1 && q <= g.ni - 2, k0, g.nk);
+        }
+        s1b[pb][r][lane] = s_new;
+        /* sweep 2 of plane a-2: its row neighbours were published one step ago */
+        {
+            const int q = a - 2;
+            const float4 jm = s1b[pb ^ 1][rm][lane], jp = s1b[pb ^ 1][rp][lane];
+            const float left = __shfl_up(s_c.w, 1, 64), right = __shfl_down(s_c.x, 1, 64);
+            const float4 o = jacobi_pt4(s_m, s_new, jm, jp, left, s_c, right, d2, hSq, sixth, omega,
+                                        row_upd && q >= 1 && q <= g.ni - 2, k0, g.nk);
+            if (own && q >= i0 && q < i1)
+                st4(vout + g.plane * q + col, o);
+        }
+        in_m = in_c;
+        in_c = in_p;
+        s_m = s_c;
+        s_c = s_new;
+        d2 = d1;
+    }
+}
+
 __device__ __forceinline__ double wave_sum32(double x)
 {
 #pragma unroll
@@ -470,7 +551,22 @@ static void e_jacobi(mg3d32_ctx *ctx, int level, int iters)
     Level32 &l = ctx->lv[level];
     const int gx = ((l.g.nk + 3) / 4 + 63) / 64, gy = (l.g.nj + 3) / 4;
     const int chunk = chunk_for(l.g.ni, (long long)gx * gy);
-    for (int it = 0; it < iters; it++) {
+    int it = 0;
+    static const bool no_pairs = getenv("MG3D_F32_NO_PAIRS") && getenv("MG3D_F32_NO_PAIRS")[0] == '1';
+    if (!no_pairs && l.g.N >= 33) { /* sweeps in pairs: one pass over HBM for two */
+        const int px = (l.g.nk + J2_OUT_COLS - 1) / J2_OUT_COLS, py = (l.g.nj + J2_OUT_ROWS - 1) / J2_OUT_ROWS;
+        int ch = 128;
+        while (ch > 8 && (long long)px * py * ((l.g.ni + ch - 1) / ch) < 1024)
+            ch /= 2;
+        for (; it + 2 <= iters; it += 2) {
+            hipLaunchKernelGGL(jacobi32x2_kernel, dim3(px, py, (l.g.ni + ch - 1) / ch), dim3(64, J2_ROWS, 1), 0,
+                               ctx->stream, l.g, l.f[MG3D_U], l.f[MG3D_D], l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, ch);
+            float *t = l.f[MG3D_U];
+            l.f[MG3D_U] = l.alt;
+            l.alt = t;
+        }
+    }
+    for (; it < iters; it++) {
         hipLaunchKernelGGL(jacobi32_kernel, dim3(gx, gy, (l.g.ni + chunk - 1) / chunk), dim3(64, 4, 1), 0, ctx->stream,
                            l.g, l.f[MG3D_U], l.f[MG3D_D], l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, chunk);
         float *t = l.f[MG3D_U];

@@ -107,26 +107,44 @@ def test_f32_solution_agrees_with_the_pinned_double_path():
     assert n[-1] < 2 * n.min()  # parked at the binary32 floor, not drifting
 
 
-def test_large_level_shapes():
-    """257^3 and a 1025-wide row pitch (float4 lanes, partial last vector): operators against numpy slices."""
-    c, L = 9, 6  # 257^3
+def jacobi_np(u, d, N, omega=OMEGA):
+    U, D = u.reshape(N, N, N), d.reshape(N, N, N)
+    h = np.float32(1.0 / (N - 1))
+    ssum = U[:-2, 1:-1, 1:-1] + U[2:, 1:-1, 1:-1]
+    ssum = ssum + U[1:-1, :-2, 1:-1]
+    ssum = ssum + U[1:-1, 2:, 1:-1]
+    ssum = ssum + U[1:-1, 1:-1, :-2]
+    ssum = ssum + U[1:-1, 1:-1, 2:]
+    ssum = ssum - (h * h) * D[1:-1, 1:-1, 1:-1]
+    gs = np.float32(1.0) / np.float32(6.0) * ssum
+    want = U.copy()
+    want[1:-1, 1:-1, 1:-1] = U[1:-1, 1:-1, 1:-1] + np.float32(omega) * (gs - U[1:-1, 1:-1, 1:-1])
+    return want.reshape(-1)
+
+
+@pytest.mark.parametrize("c,L", [(9, 6), (5, 7), (3, 8)])
+def test_large_level_shapes(c, L):
+    """257^3 (three hierarchies): partial last vectors and tiles of the single-sweep and the paired-sweep kernels (one, two,
+    three and four sweeps: pairs, pair + single) against numpy slices."""
     with M.Solver32(c, L, 2, OMEGA) as s:
         top = L - 1
         N = s.level_n(top)
         u, d = rnd(N, 11), rnd(N, 12)
-        s.upload(MG3D_U, top, u)
         s.upload(MG3D_D, top, d)
-        s.smooth(top, 1)
-        got = s.download(MG3D_U, top).reshape(N, N, N)
-        U, D = u.reshape(N, N, N), d.reshape(N, N, N)
-        h = np.float32(1.0 / (N - 1))
-        ssum = U[:-2, 1:-1, 1:-1] + U[2:, 1:-1, 1:-1]
-        ssum = ssum + U[1:-1, :-2, 1:-1]
-        ssum = ssum + U[1:-1, 2:, 1:-1]
-        ssum = ssum + U[1:-1, 1:-1, :-2]
-        ssum = ssum + U[1:-1, 1:-1, 2:]
-        ssum = ssum - (h * h) * D[1:-1, 1:-1, 1:-1]
-        gs = np.float32(1.0) / np.float32(6.0) * ssum
-        want = U.copy()
-        want[1:-1, 1:-1, 1:-1] = U[1:-1, 1:-1, 1:-1] + np.float32(OMEGA) * (gs - U[1:-1, 1:-1, 1:-1])
-        assert np.array_equal(got, want)
+        want = u
+        for iters in (1, 2, 3, 4):
+            s.upload(MG3D_U, top, u)
+            s.smooth(top, iters)
+            want = jacobi_np(want, d, N)
+            assert np.array_equal(s.download(MG3D_U, top), want), f"{iters} sweeps at {N}^3"
+
+
+def test_paired_and_single_sweeps_agree(monkeypatch):
+    """MG3D_F32_NO_PAIRS=1 runs every sweep as its own launch: same bits as the two-sweeps-per-launch kernel."""
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MG3D_F32_NO_PAIRS", flag)
+        with M.Solver32(9, 5, 2, OMEGA) as s:
+            s.setup_test_problem()
+            res.append((s.vcycles(4), s.download(MG3D_U, 4)))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
