@@ -293,6 +293,122 @@ __global__ void __launch_bounds__(256) restrict32_kernel(Geom gf, const float *_
     dc[gidx32(gc, ic, jc, kc)] = val;
 }
 
+/* Residual and full-weighting restriction in one pass (r never travels to HBM).  Same tile and plane ring as the
+ * paired sweep: stage 1 forms the residual of fine plane q from the input planes q-1, q, q+1 and publishes it in
+ * LDS; stage 2, one thread per coarse point of the tile (6 x 124), adds that plane's nine weighted values to
+ * the running sum of the coarse plane(s) it belongs to -- plane 2ic-1 starts coarse plane ic (ti = 0), plane 2ic
+ * continues it, plane 2ic+1 completes and stores it -- which is the reference's ti, tj, tk order from 0
+ * (mg_3d.h:973-989).  Coarse faces (injection) are left to restrict32_faces_kernel. */
+__global__ void __launch_bounds__(1024) residual_restrict32_kernel(Geom g, const float *__restrict__ v,
+                                                                   const float *__restrict__ d, float invHsq, Geom gc,
+                                                                   float *__restrict__ dc, int cchunk)
+{
+    __shared__ float4 inp[2][J2_ROWS][64];
+    __shared__ float rb[2][J2_ROWS][256];
+    const int lane = threadIdx.x, r = threadIdx.y, tid = r * 64 + lane;
+    const int jt0 = (int)blockIdx.y * J2_OUT_ROWS - 2, kt0 = (int)blockIdx.x * J2_OUT_COLS - 4;
+    const int j = jt0 + r, k0 = kt0 + 4 * lane;
+    /* coarse planes [c0, c1) of this block; fine planes 2c0-1 .. 2c1-1 are needed */
+    const int c0 = max(1, (int)blockIdx.z * cchunk), c1 = min((int)(blockIdx.z + 1) * cchunk, gc.ni - 1);
+    if (c0 >= c1)
+        return;
+    const bool in_dom = j >= 0 && j < g.nj && k0 >= 0 && k0 < g.nk;
+    const bool row_int = j >= 1 && j <= g.nj - 2;
+    const long long col = (long long)g.pitch * j + k0;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load = [&](const float *base, int i) { return (in_dom && i >= 0 && i < g.ni) ? ld4(base + g.plane * i + col) : zero; };
+    const int rm = r > 0 ? r - 1 : r, rp = r < J2_ROWS - 1 ? r + 1 : r;
+    /* stage 2 mapping: coarse point (jcl, kcl) of the tile, fine centre at tile row 2 + 2 jcl, tile column 4 + 2 kcl */
+    const int jcl = tid / 124, kcl = tid - jcl * 124;
+    const int jc = (jt0 + 2) / 2 + jcl, kc = (kt0 + 4) / 2 + kcl;
+    const bool cown = tid < 6 * 124 && jc >= 1 && jc <= gc.nj - 2 && kc >= 1 && kc <= gc.nk - 2;
+    const int fr = 2 + 2 * jcl, fc = 4 + 2 * kcl; /* centre in tile coordinates */
+    float accA = 0.f, accB = 0.f; /* coarse plane being completed / the one after it */
+    const int q0 = 2 * c0 - 1, q1 = 2 * c1 - 1; /* fine planes q0 .. q1 inclusive */
+    float4 in_m = load(v, q0 - 1), in_c = load(v, q0);
+    for (int q = q0; q <= q1; q++) {
+        const float4 in_p = load(v, q + 1);
+        const float4 dd = load(d, q);
+        const int pb = q & 1;
+        inp[pb][r][lane] = in_c;
+        __syncthreads();
+        {
+            const float4 jm = inp[pb][rm][lane], jp = inp[pb][rp][lane];
+            const float left = __shfl_up(in_c.w, 1, 64), right = __shfl_down(in_c.x, 1, 64);
+            const float hv[6] = {left, in_c.x, in_c.y, in_c.z, in_c.w, right};
+            const float bl[4] = {in_m.x, in_m.y, in_m.z, in_m.w}, ab[4] = {in_p.x, in_p.y, in_p.z, in_p.w};
+            const float jmv[4] = {jm.x, jm.y, jm.z, jm.w}, jpv[4] = {jp.x, jp.y, jp.z, jp.w};
+            const float dv[4] = {dd.x, dd.y, dd.z, dd.w};
+            float df[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int k = k0 + c;
+                const float s = sum6(bl[c], ab[c], jmv[c], jpv[c], hv[c], hv[c + 2]) - 6 * hv[c + 1];
+                /* r is zero where the reference never writes it (boundary points, mg_3d.h:824-825) */
+                df[c] = (row_int && k >= 1 && k <= g.nk - 2) ? dv[c] - invHsq * s : 0.f;
+            }
+            *reinterpret_cast<float4 *>(&rb[pb][r][4 * lane]) = make_float4(df[0], df[1], df[2], df[3]);
+        }
+        __syncthreads();
+        if (cown) {
+            /* this plane's nine products, tj then tk ascending; the i-weight is 1/2 on the centre plane, else 1/4 */
+            const float wi = (q & 1) ? 0.25f : 0.5f;
+            float p9[9];
+#pragma unroll
+            for (int tj = 0; tj < 3; tj++)
+#pragma unroll
+                for (int tk = 0; tk < 3; tk++) {
+                    const float w = (wi * (tj == 1 ? 0.5f : 0.25f)) * (tk == 1 ? 0.5f : 0.25f);
+                    p9[tj * 3 + tk] = rb[pb][fr - 1 + tj][fc - 1 + tk] * w;
+                }
+            if (q & 1) {
+                /* completes coarse plane (q-1)/2, starts coarse plane (q+1)/2 */
+#pragma unroll
+                for (int t = 0; t < 9; t++)
+                    accA += p9[t];
+                const int ic = (q - 1) / 2;
+                if (ic >= c0 && ic < c1)
+                    dc[gc.plane * ic + (long long)gc.pitch * jc + kc] = accA;
+                accB = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; t++)
+                    accB += p9[t];
+                accA = accB;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 9; t++)
+                    accA += p9[t];
+            }
+        }
+        in_m = in_c;
+        in_c = in_p;
+    }
+}
+
+/* injection on the six coarse faces (mg_3d.h:879-958) from the stored r (whose boundary entries nothing writes) */
+__global__ void __launch_bounds__(256) restrict32_faces_kernel(Geom gf, const float *__restrict__ r, Geom gc,
+                                                               float *__restrict__ dc)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x, a = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
+    if (a >= gc.ni || b >= gc.ni)
+        return;
+    int ic, jc, kc;
+    if (f < 2) {
+        ic = f == 0 ? 0 : gc.ni - 1;
+        jc = a;
+        kc = b;
+    } else if (f < 4) {
+        ic = a;
+        jc = f == 2 ? 0 : gc.nj - 1;
+        kc = b;
+    } else {
+        ic = a;
+        jc = b;
+        kc = f == 4 ? 0 : gc.nk - 1;
+    }
+    dc[gidx32(gc, ic, jc, kc)] = r[gidx32(gf, 2 * ic, 2 * jc, 2 * kc)];
+}
+
 /* prolongateAndCorrectError (mg_3d.h:1000-1145) in binary32, cell form: a thread owns the 2 x 2 fine points
  * above one coarse cell and marches along i; parents summed in the reference's order per parity class */
 __global__ void __launch_bounds__(256) prolong32_kernel(Geom gc, const float *__restrict__ ec, Geom gf,
@@ -599,6 +715,20 @@ static void e_restrict(mg3d32_ctx *ctx, int level)
                        ctx->stream, lf.g, lf.f[MG3D_R], lc.g, lc.f[MG3D_D]);
 }
 
+static void e_residual_restrict(mg3d32_ctx *ctx, int level)
+{
+    Level32 &lf = ctx->lv[level], &lc = ctx->lv[level - 1];
+    const int px = (lf.g.nk + J2_OUT_COLS - 1) / J2_OUT_COLS, py = (lf.g.nj + J2_OUT_ROWS - 1) / J2_OUT_ROWS;
+    int cch = 64; /* coarse planes per block */
+    while (cch > 4 && (long long)px * py * ((lc.g.ni + cch - 1) / cch) < 1024)
+        cch /= 2;
+    hipLaunchKernelGGL(residual_restrict32_kernel, dim3(px, py, (lc.g.ni + cch - 1) / cch), dim3(64, J2_ROWS, 1), 0,
+                       ctx->stream, lf.g, lf.f[MG3D_U], lf.f[MG3D_D], lf.invHsq, lc.g, lc.f[MG3D_D], cch);
+    const int m = lc.g.ni;
+    hipLaunchKernelGGL(restrict32_faces_kernel, dim3((m + 63) / 64, (m + 3) / 4, 6), dim3(64, 4, 1), 0, ctx->stream,
+                       lf.g, lf.f[MG3D_R], lc.g, lc.f[MG3D_D]);
+}
+
 static void e_prolong(mg3d32_ctx *ctx, int level)
 {
     Level32 &lf = ctx->lv[level], &lc = ctx->lv[level - 1];
@@ -640,8 +770,13 @@ static int e_vcycle(mg3d32_ctx *ctx, int q, int slot)
     if (q == 0)
         return e_coarse_solve(ctx);
     e_jacobi(ctx, q, ctx->iters);                       /* :1282 */
-    e_residual(ctx, q, true, ctx->sumsq_slots - 1);     /* :1294 (its norm is dropped) */
-    e_restrict(ctx, q);                                 /* :1310 */
+    static const bool no_fuse = getenv("MG3D_F32_NO_FUSE") && getenv("MG3D_F32_NO_FUSE")[0] == '1';
+    if (!no_fuse && ctx->lv[q].g.N >= 33) {
+        e_residual_restrict(ctx, q);                    /* :1294 + :1310, r not stored */
+    } else {
+        e_residual(ctx, q, true, ctx->sumsq_slots - 1); /* :1294 (its norm is dropped) */
+        e_restrict(ctx, q);                             /* :1310 */
+    }
     Level32 &lc = ctx->lv[q - 1];
     (void)hipMemsetAsync(lc.f[MG3D_U], 0, lc.elems * sizeof(float), ctx->stream); /* :1258 */
     CHK(e_vcycle(ctx, q - 1, ctx->sumsq_slots - 1));    /* :1321 */

@@ -139,11 +139,13 @@ def test_large_level_shapes(c, L):
             assert np.array_equal(s.download(MG3D_U, top), want), f"{iters} sweeps at {N}^3"
 
 
-def test_paired_and_single_sweeps_agree(monkeypatch):
-    """MG3D_F32_NO_PAIRS=1 runs every sweep as its own launch: same bits as the two-sweeps-per-launch kernel."""
+@pytest.mark.parametrize("knob", ["MG3D_F32_NO_PAIRS", "MG3D_F32_NO_FUSE"])
+def test_fused_and_separate_launches_agree(monkeypatch, knob):
+    """MG3D_F32_NO_PAIRS=1 runs every sweep as its own launch, MG3D_F32_NO_FUSE=1 stores r and restricts it in a
+    second launch: same bits as the two-sweeps-per-launch and the residual+restriction kernels."""
     res = []
     for flag in ("0", "1"):
-        monkeypatch.setenv("MG3D_F32_NO_PAIRS", flag)
+        monkeypatch.setenv(knob, flag)
         with M.Solver32(9, 5, 2, OMEGA) as s:
             s.setup_test_problem()
             res.append((s.vcycles(4), s.download(MG3D_U, 4)))
