@@ -147,59 +147,7 @@ __device__ __forceinline__ float4 jacobi_pt4(float4 below, float4 above, float4 
 }
 
 constexpr int J2_ROWS = 16, J2_OUT_ROWS = 12, J2_OUT_COLS = 248;
-
-__global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *__restrict__ vin,
-                                                          const float *__restrict__ d, float *__restrict__ vout,
-                                                          float hSq, float sixth, float omega, int chunk)
-{
-    __shared__ float4 inp[2][J2_ROWS][64];
-    __shared__ float4 s1b[2][J2_ROWS][64];
-    const int lane = threadIdx.x, r = threadIdx.y;
-    const int j = (int)blockIdx.y * J2_OUT_ROWS - 2 + r;
-    const int k0 = (int)blockIdx.x * J2_OUT_COLS - 4 + 4 * lane;
-    const int i0 = blockIdx.z * chunk, i1 = min(i0 + chunk, g.ni);
-    const bool in_dom = j >= 0 && j < g.nj && k0 >= 0 && k0 < g.nk; /* pitch covers a partial last vector */
-    const bool row_upd = j >= 1 && j <= g.nj - 2;
-    const bool own = in_dom && r >= 2 && r < 2 + J2_OUT_ROWS && lane >= 1 && lane <= 62;
-    const long long col = (long long)g.pitch * j + k0;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load = [&](const float *base, int i) { return (in_dom && i >= 0 && i < g.ni) ? ld4(base + g.plane * i + col) : zero; };
-    const int rm = r > 0 ? r - 1 : r, rp = r < J2_ROWS - 1 ? r + 1 : r;
-    /* registers: input planes a-2 (in_m), a-1 (in_c); sweep-1 planes a-3 (s_m), a-2 (s_c); d of plane a-2 */
-    float4 in_m = load(vin, i0 - 3), in_c = load(vin, i0 - 2), s_m = zero, s_c = zero, d2 = zero;
-    for (int a = i0 - 1; a <= i1 + 1; a++) {
-        const float4 in_p = load(vin, a);
-        const float4 d1 = load(d, a - 1);
-        const int pb = a & 1;
-        inp[pb][r][lane] = in_c;
-        __syncthreads();
-        /* sweep 1 of plane a-1 */
-        float4 s_new;
-        {
-            const float4 jm = inp[pb][rm][lane], jp = inp[pb][rp][lane];
-            const float left = __shfl_up(in_c.w, 1, 64), right = __shfl_down(in_c.x, 1, 64);
-            const int q = a - 1;
-            s_new = jacobi_pt4(in_m, in_p, jm, jp, left, in_c, right, d1, hSq, sixth, omega,
-                               row_upd && q >= 1 && q <= g.ni - 2, k0, g.nk);
-        }
-        s1b[pb][r][lane] = s_new;
-        /* sweep 2 of plane a-2: its row neighbours were published one step ago */
-        {
-            const int q = a - 2;
-            const float4 jm = s1b[pb ^ 1][rm][lane], jp = s1b[pb ^ 1][rp][lane];
-            const float left = __shfl_up(s_c.w, 1, 64), right = __shfl_down(s_c.x, 1, 64);
-            const float4 o = jacobi_pt4(s_m, s_new, jm, jp, left, s_c, right, d2, hSq, sixth, omega,
-                                        row_upd && q >= 1 && q <= g.ni - 2, k0, g.nk);
-            if (own && q >= i0 && q < i1)
-                st4(vout + g.plane * q + col, o);
-        }
-        in_m = in_c;
-        in_c = in_p;
-        s_m = s_c;
-        s_c = s_new;
-        d2 = d1;
-    }
-}
+constexpr int J2N_OUT_ROWS = 10; /* with the residual norm as a third stage the tile gives up one more ring of rows */
 
 __device__ __forceinline__ double wave_sum32(double x)
 {
@@ -208,6 +156,119 @@ __device__ __forceinline__ double wave_sum32(double x)
         x += __shfl_down(x, off, 64);
     return x;
 }
+
+/* NORM: a third stage forms the residual of the twice-smoothed field (plane a-3, from sweep-2 planes a-4, a-3, a-2)
+ * and accumulates (double)diff^2 over the block's own points: the level's norm without another pass over HBM. */
+template <bool NORM>
+__global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *__restrict__ vin,
+                                                          const float *__restrict__ d, float *__restrict__ vout,
+                                                          float hSq, float sixth, float omega, float invHsq,
+                                                          double *__restrict__ partials, int chunk)
+{
+    constexpr int OUT_ROWS = NORM ? J2N_OUT_ROWS : J2_OUT_ROWS, R0 = NORM ? 3 : 2;
+    /* one plane each of the input, the sweep-1 and (NORM) the sweep-2 field: 32 / 48 KB, two blocks per CU.
+     * Per step: publish the input plane | barrier | every thread fetches the row neighbours it needs of all
+     * three planes | barrier | compute the stages and publish their planes for the next step. */
+    __shared__ float4 inp[J2_ROWS][64];
+    __shared__ float4 s1b[J2_ROWS][64];
+    __shared__ float4 s2b[NORM ? J2_ROWS : 1][NORM ? 64 : 1];
+    __shared__ double red[16];
+    const int lane = threadIdx.x, r = threadIdx.y;
+    const int j = (int)blockIdx.y * OUT_ROWS - R0 + r;
+    const int k0 = (int)blockIdx.x * J2_OUT_COLS - 4 + 4 * lane;
+    const int i0 = blockIdx.z * chunk, i1 = min(i0 + chunk, g.ni);
+    const bool in_dom = j >= 0 && j < g.nj && k0 >= 0 && k0 < g.nk; /* pitch covers a partial last vector */
+    const bool row_upd = j >= 1 && j <= g.nj - 2;
+    const bool own = in_dom && r >= R0 && r < R0 + OUT_ROWS && lane >= 1 && lane <= 62;
+    const long long col = (long long)g.pitch * j + k0;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load = [&](const float *base, int i) { return (in_dom && i >= 0 && i < g.ni) ? ld4(base + g.plane * i + col) : zero; };
+    const int rm = r > 0 ? r - 1 : r, rp = r < J2_ROWS - 1 ? r + 1 : r;
+    /* registers: input planes a-2 (in_m), a-1 (in_c); sweep-1 planes a-3 (s_m), a-2 (s_c); d of planes a-2, a-3;
+     * NORM: sweep-2 planes a-4 (o_m), a-3 (o_c) */
+    const int a0 = i0 - (NORM ? 2 : 1), a1 = i1 + (NORM ? 2 : 1);
+    float4 in_m = load(vin, a0 - 2), in_c = load(vin, a0 - 1), s_m = zero, s_c = zero, d2 = zero, d3 = zero;
+    float4 o_m = zero, o_c = zero;
+    double acc = 0.;
+    s1b[r][lane] = zero;
+    if constexpr (NORM)
+        s2b[r][lane] = zero;
+    for (int a = a0; a <= a1; a++) {
+        const float4 in_p = load(vin, a);
+        const float4 d1 = load(d, a - 1);
+        inp[r][lane] = in_c;
+        __syncthreads();
+        const float4 ijm = inp[rm][lane], ijp = inp[rp][lane];   /* input plane a-1 */
+        const float4 sjm = s1b[rm][lane], sjp = s1b[rp][lane];   /* sweep-1 plane a-2, published one step ago */
+        float4 ojm = zero, ojp = zero;
+        if constexpr (NORM) {
+            ojm = s2b[rm][lane];                                 /* sweep-2 plane a-3 */
+            ojp = s2b[rp][lane];
+        }
+        __syncthreads();
+        /* sweep 1 of plane a-1 */
+        float4 s_new;
+        {
+            const float left = __shfl_up(in_c.w, 1, 64), right = __shfl_down(in_c.x, 1, 64);
+            const int q = a - 1;
+            s_new = jacobi_pt4(in_m, in_p, ijm, ijp, left, in_c, right, d1, hSq, sixth, omega,
+                               row_upd && q >= 1 && q <= g.ni - 2, k0, g.nk);
+        }
+        s1b[r][lane] = s_new;
+        /* sweep 2 of plane a-2 */
+        float4 o;
+        {
+            const int q = a - 2;
+            const float left = __shfl_up(s_c.w, 1, 64), right = __shfl_down(s_c.x, 1, 64);
+            o = jacobi_pt4(s_m, s_new, sjm, sjp, left, s_c, right, d2, hSq, sixth, omega,
+                           row_upd && q >= 1 && q <= g.ni - 2, k0, g.nk);
+            if (own && q >= i0 && q < i1)
+                st4(vout + g.plane * q + col, o);
+        }
+        if constexpr (NORM) {
+            s2b[r][lane] = o;
+            /* residual of plane a-3 (mg_3d.h:819-821) */
+            const int q = a - 3;
+            const float left = __shfl_up(o_c.w, 1, 64), right = __shfl_down(o_c.x, 1, 64);
+            if (own && row_upd && q >= i0 && q < i1 && q >= 1 && q <= g.ni - 2) {
+                const float hv[6] = {left, o_c.x, o_c.y, o_c.z, o_c.w, right};
+                const float bl[4] = {o_m.x, o_m.y, o_m.z, o_m.w}, ab[4] = {o.x, o.y, o.z, o.w};
+                const float jmv[4] = {ojm.x, ojm.y, ojm.z, ojm.w}, jpv[4] = {ojp.x, ojp.y, ojp.z, ojp.w};
+                const float dv[4] = {d3.x, d3.y, d3.z, d3.w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int k = k0 + c;
+                    if (k >= 1 && k <= g.nk - 2) {
+                        const float ssum = sum6(bl[c], ab[c], jmv[c], jpv[c], hv[c], hv[c + 2]) - 6 * hv[c + 1];
+                        const float diff = dv[c] - invHsq * ssum;
+                        acc += (double)diff * (double)diff;
+                    }
+                }
+            }
+            o_m = o_c;
+            o_c = o;
+            d3 = d2;
+        }
+        in_m = in_c;
+        in_c = in_p;
+        s_m = s_c;
+        s_c = s_new;
+        d2 = d1;
+    }
+    if constexpr (NORM) {
+        acc = wave_sum32(acc);
+        if (lane == 0)
+            red[r] = acc;
+        __syncthreads();
+        if (r == 0 && lane == 0) {
+            double t = 0.;
+            for (int x = 0; x < J2_ROWS; x++)
+                t += red[x];
+            partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+        }
+    }
+}
+
 
 /* diff = d - invHsq * (sum6 - 6 v) (mg_3d.h:819-821) in binary32; res (optional) on the interior only;
  * per-block partial sums of (double)diff^2 in a fixed order */
@@ -662,33 +723,54 @@ static int chunk_for(int planes, long long blocks_per_plane, long long want = 40
     return chunk;
 }
 
-static void e_jacobi(mg3d32_ctx *ctx, int level, int iters)
+/* `iters` sweeps.  norm_slot >= 0: the caller wants ||d - A u|| of the result in sumsq[norm_slot]; returns true when
+ * the last launch delivered it (paired sweep with the residual as third stage), false when a residual launch
+ * still has to follow. */
+static bool e_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot = -1)
 {
     Level32 &l = ctx->lv[level];
     const int gx = ((l.g.nk + 3) / 4 + 63) / 64, gy = (l.g.nj + 3) / 4;
     const int chunk = chunk_for(l.g.ni, (long long)gx * gy);
     int it = 0;
+    bool normed = false;
     static const bool no_pairs = getenv("MG3D_F32_NO_PAIRS") && getenv("MG3D_F32_NO_PAIRS")[0] == '1';
+    static const bool no_fuse = getenv("MG3D_F32_NO_FUSE") && getenv("MG3D_F32_NO_FUSE")[0] == '1';
+    auto swap = [&]() {
+        float *t = l.f[MG3D_U];
+        l.f[MG3D_U] = l.alt;
+        l.alt = t;
+    };
     if (!no_pairs && l.g.N >= 33) { /* sweeps in pairs: one pass over HBM for two */
-        const int px = (l.g.nk + J2_OUT_COLS - 1) / J2_OUT_COLS, py = (l.g.nj + J2_OUT_ROWS - 1) / J2_OUT_ROWS;
-        int ch = 128;
-        while (ch > 8 && (long long)px * py * ((l.g.ni + ch - 1) / ch) < 1024)
-            ch /= 2;
+        const int px = (l.g.nk + J2_OUT_COLS - 1) / J2_OUT_COLS;
         for (; it + 2 <= iters; it += 2) {
-            hipLaunchKernelGGL(jacobi32x2_kernel, dim3(px, py, (l.g.ni + ch - 1) / ch), dim3(64, J2_ROWS, 1), 0,
-                               ctx->stream, l.g, l.f[MG3D_U], l.f[MG3D_D], l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, ch);
-            float *t = l.f[MG3D_U];
-            l.f[MG3D_U] = l.alt;
-            l.alt = t;
+            const bool with_norm = norm_slot >= 0 && !no_fuse && it + 2 == iters;
+            const int py = (l.g.nj + (with_norm ? J2N_OUT_ROWS : J2_OUT_ROWS) - 1) / (with_norm ? J2N_OUT_ROWS : J2_OUT_ROWS);
+            int ch = 128;
+            while (ch > 8 && (long long)px * py * ((l.g.ni + ch - 1) / ch) < 1024)
+                ch /= 2;
+            while (with_norm && (long long)px * py * ((l.g.ni + ch - 1) / ch) > MG3D_MAX_PARTIALS)
+                ch *= 2;
+            const dim3 grid(px, py, (l.g.ni + ch - 1) / ch);
+            if (with_norm) {
+                hipLaunchKernelGGL(jacobi32x2_kernel<true>, grid, dim3(64, J2_ROWS, 1), 0, ctx->stream, l.g, l.f[MG3D_U],
+                                   l.f[MG3D_D], l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, l.invHsq, ctx->partials, ch);
+                k_fold(ctx->partials, (int)(grid.x * grid.y * grid.z), ctx->sumsq + norm_slot, ctx->stream);
+                normed = true;
+            } else {
+                hipLaunchKernelGGL(jacobi32x2_kernel<false>, grid, dim3(64, J2_ROWS, 1), 0, ctx->stream, l.g,
+                                   l.f[MG3D_U], l.f[MG3D_D], l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, l.invHsq,
+                                   (double *)nullptr, ch);
+            }
+            swap();
         }
     }
     for (; it < iters; it++) {
         hipLaunchKernelGGL(jacobi32_kernel, dim3(gx, gy, (l.g.ni + chunk - 1) / chunk), dim3(64, 4, 1), 0, ctx->stream,
                            l.g, l.f[MG3D_U], l.f[MG3D_D], l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, chunk);
-        float *t = l.f[MG3D_U];
-        l.f[MG3D_U] = l.alt;
-        l.alt = t;
+        swap();
+        normed = false;
     }
+    return normed;
 }
 
 static void e_residual(mg3d32_ctx *ctx, int level, bool store, int slot)
@@ -781,8 +863,10 @@ static int e_vcycle(mg3d32_ctx *ctx, int q, int slot)
     (void)hipMemsetAsync(lc.f[MG3D_U], 0, lc.elems * sizeof(float), ctx->stream); /* :1258 */
     CHK(e_vcycle(ctx, q - 1, ctx->sumsq_slots - 1));    /* :1321 */
     e_prolong(ctx, q);                                  /* :1331 */
-    e_jacobi(ctx, q, ctx->iters);                       /* :1341 */
-    e_residual(ctx, q, false, slot);                    /* :1354 */
+    /* :1341 + :1354; below the top level the reference drops the norm (:1320), so it is not formed there */
+    const bool top = q == ctx->L - 1;
+    if (!e_jacobi(ctx, q, ctx->iters, top ? slot : -1) && top)
+        e_residual(ctx, q, false, slot);
     return MG3D_OK;
 }
 
