@@ -18,6 +18,8 @@
 #ifndef MG3D_H
 #define MG3D_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -188,6 +190,9 @@ void mg3d_lu_factor(double *a, int n);
 double mg3d_l2norm_host(const double *d, long n);
 void mg3d_smooth_edges_host(double *u, int N);
 int mg3d_write_vtk(const char *file_name, const double *grid, double h, int N);
+/* zero-filled page-locked host memory (hipHostMalloc): arrays the facade moves across PCIe on every solve */
+int mg3d_host_alloc(size_t bytes, void **out);
+int mg3d_host_free(void *p);
 
 /* ---- single precision / damped Jacobi / F-cycle variant (BASELINE configs[4]) --------------------------
  * PARITY UNPINNED: the reference has no fp32 arithmetic and no Jacobi smoother; its FMG start exists only as

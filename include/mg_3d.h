@@ -57,6 +57,7 @@ static mg3d_ctx *mg3d_solver_ctx_ = NULL;
 static int mg3d_host_newer_ = 1;   /* host finest u/d written since the last upload */
 static int mg3d_device_newer_ = 0; /* device u newer than the host mirror */
 static double mg3d_team_norm_ = 0.;
+static int mg3d_pinned_top_ = 0;   /* finest u and d come from mg3d_host_alloc */
 
 /* allocGridLevels, mg_3d.h:30-48: level i has ((N-1)*2^i+1)^3 zeroed doubles */
 static inline void allocGridLevels(double ***lv, const int nLevels, const int N)
@@ -234,6 +235,20 @@ static inline void SolverInitialize(int argc, char **argv)
     allocGridLevels(&u, numLevels, coarseGridNum);
     allocGridLevels(&d, numLevels, coarseGridNum);
     allocGridLevels(&r, numLevels, coarseGridNum);
+    /* the finest u and d cross PCIe around every solve: page-locked memory from the library for those two */
+    {
+        const size_t nf = (size_t)finestOneSideNum * finestOneSideNum * finestOneSideNum * sizeof(double);
+        void *pu = NULL, *pd = NULL;
+        if (mg3d_host_alloc(nf, &pu) == 0 && mg3d_host_alloc(nf, &pd) == 0) {
+            free(u[numLevels - 1]);
+            free(d[numLevels - 1]);
+            u[numLevels - 1] = (double *)pu;
+            d[numLevels - 1] = (double *)pd;
+            mg3d_pinned_top_ = 1;
+        } else if (pu) {
+            (void)mg3d_host_free(pu);
+        }
+    }
     allocTimingInfo(&tInfo, numLevels);
     spacing = (double)(GRID_LENGTH) / (finestOneSideNum - 1);
 
@@ -359,6 +374,13 @@ static inline void SolverFinalize(void)
     mg3d_solver_ctx_ = NULL;
     deAllocTimingInfo(&tInfo, numLevels);
     free(A);
+    if (mg3d_pinned_top_) { /* hand the two page-locked arrays back first; the rest is calloc'ed */
+        (void)mg3d_host_free(u[numLevels - 1]);
+        (void)mg3d_host_free(d[numLevels - 1]);
+        u[numLevels - 1] = NULL;
+        d[numLevels - 1] = NULL;
+        mg3d_pinned_top_ = 0;
+    }
     deAllocGridLevels(&u, numLevels);
     deAllocGridLevels(&d, numLevels);
     deAllocGridLevels(&r, numLevels);

@@ -94,6 +94,8 @@ SIGNATURES = {
     "mg3d_l2norm_host": (C.c_double, [dp, C.c_long]),
     "mg3d_smooth_edges_host": (None, [dp, C.c_int]),
     "mg3d_write_vtk": (C.c_int, [C.c_char_p, dp, C.c_double, C.c_int]),
+    "mg3d_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "mg3d_host_free": (C.c_int, [C.c_void_p]),
     # single precision / damped Jacobi / F-cycle variant (parity unpinned)
     "mg3d32_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
     "mg3d32_destroy": (C.c_int, [C.c_void_p]),

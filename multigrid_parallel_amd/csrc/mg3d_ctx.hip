@@ -887,6 +887,30 @@ extern "C" int mg3d_timing_get(mg3d_ctx *ctx, int level, int stage, int *num_cal
     return MG3D_OK;
 }
 
+/* page-locked host arrays for the facade's finest u and d (mg_3d.h:275-293 hands their addresses to the caller,
+ * and they cross PCIe around every solve: pageable memory downloads at 15 GB/s, page-locked at PCIe rate) */
+extern "C" int mg3d_host_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0)
+        return fail(MG3D_ERR_ARG, "mg3d_host_alloc: bad arguments");
+    if (mg3d_device_count() <= 0)
+        return fail(MG3D_ERR_NO_DEVICE, "no HIP device available: libmg3d has no CPU fallback");
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess)
+        return fail(MG3D_ERR_ALLOC, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    memset(p, 0, bytes);
+    *out = p;
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_host_free(void *p)
+{
+    if (p && hipHostFree(p) != hipSuccess)
+        return fail(MG3D_ERR_HIP, "hipHostFree failed");
+    return MG3D_OK;
+}
+
 /* ----------------------------------------------- host-pointer operator forms */
 struct ScratchCtx { /* a one- or two-level context for a single host-pointer call */
     mg3d_ctx *ctx = nullptr;
