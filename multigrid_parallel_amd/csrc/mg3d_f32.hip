@@ -159,13 +159,21 @@ __device__ __forceinline__ double wave_sum32(double x)
 
 /* NORM: a third stage forms the residual of the twice-smoothed field (plane a-3, from sweep-2 planes a-4, a-3, a-2)
  * and accumulates (double)diff^2 over the block's own points: the level's norm without another pass over HBM. */
-template <bool NORM>
+/* PRO: the level's input is vin + P(ec) (prolongateAndCorrectError, mg_3d.h:1000-1145, parents in the reference's
+ * order per parity class): the coarse planes of the tile's footprint are staged in LDS (ring of three, one new plane
+ * every other step, fetched a step ahead) and every plane that enters the pipeline gets its correction on the way
+ * in -- the prolongation costs neither a launch nor a pass over the fine level. */
+constexpr int CP_ROWS = 10, CP_COLS = 130;
+
+template <bool NORM, bool PRO>
 __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *__restrict__ vin,
                                                           const float *__restrict__ d, float *__restrict__ vout,
                                                           float hSq, float sixth, float omega, float invHsq,
-                                                          double *__restrict__ partials, int chunk)
+                                                          double *__restrict__ partials, int chunk, Geom gc,
+                                                          const float *__restrict__ ec)
 {
     constexpr int OUT_ROWS = NORM ? J2N_OUT_ROWS : J2_OUT_ROWS, R0 = NORM ? 3 : 2;
+    __shared__ float cpl[PRO ? 3 : 1][PRO ? CP_ROWS : 1][PRO ? CP_COLS : 1];
     /* one plane each of the input, the sweep-1 and (NORM) the sweep-2 field: 32 / 48 KB, two blocks per CU.
      * Per step: publish the input plane | barrier | every thread fetches the row neighbours it needs of all
      * three planes | barrier | compute the stages and publish their planes for the next step. */
@@ -187,17 +195,121 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
     /* registers: input planes a-2 (in_m), a-1 (in_c); sweep-1 planes a-3 (s_m), a-2 (s_c); d of planes a-2, a-3;
      * NORM: sweep-2 planes a-4 (o_m), a-3 (o_c) */
     const int a0 = i0 - (NORM ? 2 : 1), a1 = i1 + (NORM ? 2 : 1);
-    float4 in_m = load(vin, a0 - 2), in_c = load(vin, a0 - 1), s_m = zero, s_c = zero, d2 = zero, d3 = zero;
+    /* ---- PRO: coarse staging */
+    const int tid = r * 64 + lane;
+    const int jt0 = (int)blockIdx.y * OUT_ROWS - R0, kt0 = (int)blockIdx.x * J2_OUT_COLS - 4;
+    const int jcb = (jt0 - (jt0 & 1)) / 2, kcb = kt0 / 2; /* floor: jt0 may be odd and negative, kt0 is a multiple of 4 */
+    auto slot_of = [](int c) { return ((c % 3) + 3) % 3; };
+    auto coarse_fetch = [&](int c, float(&buf)[2]) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int idx = tid + t * 1024, row = idx / CP_COLS, cc = idx - row * CP_COLS;
+            const int jc = jcb + row, kc = kcb + cc;
+            const bool ok = idx < CP_ROWS * CP_COLS && c >= 0 && c < gc.ni && jc >= 0 && jc < gc.nj && kc >= 0 && kc < gc.nk;
+            buf[t] = ok ? ec[gc.plane * c + (long long)gc.pitch * jc + kc] : 0.f;
+        }
+    };
+    auto coarse_put = [&](int c, const float(&buf)[2]) {
+        const int sl = slot_of(c);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int idx = tid + t * 1024;
+            if (idx < CP_ROWS * CP_COLS)
+                (&cpl[sl][0][0])[idx] = buf[t];
+        }
+    };
+    /* v_in(plane i) = u + P(ec): the staged planes cover coarse_lo(i) and, for odd i, the one above */
+    auto load_in = [&](int i) {
+        float4 v = load(vin, i);
+        if constexpr (PRO) {
+            if (in_dom && i >= 0 && i < g.ni) {
+                const int oi = i & 1, oj = j & 1;
+                const int cl = (i - oi) / 2, lr = (j - oj) / 2 - jcb, lc = 2 * lane;
+                const int s0 = slot_of(cl), s1 = slot_of(cl + 1);
+                float E0[2][3], E1[2][3];
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                    for (int cc = 0; cc < 3; cc++) {
+                        E0[rr][cc] = cpl[s0][lr + rr][lc + cc];
+                        E1[rr][cc] = cpl[s1][lr + rr][lc + cc];
+                    }
+                float t[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int cc = c >> 1;
+                    if (!(c & 1)) { /* k even */
+                        if (!oi && !oj)
+                            t[c] = E0[0][cc];
+                        else if (!oi)
+                            t[c] = (E0[0][cc] + E0[1][cc]) * 0.5f;
+                        else if (!oj)
+                            t[c] = (E0[0][cc] + E1[0][cc]) * 0.5f;
+                        else
+                            t[c] = (((E0[0][cc] + E0[1][cc]) + E1[0][cc]) + E1[1][cc]) * 0.25f;
+                    } else { /* k odd */
+                        if (!oi && !oj) {
+                            t[c] = (E0[0][cc] + E0[0][cc + 1]) * 0.5f;
+                        } else if (!oi) {
+                            t[c] = (((E0[0][cc] + E0[1][cc]) + E0[0][cc + 1]) + E0[1][cc + 1]) * 0.25f;
+                        } else if (!oj) {
+                            t[c] = (((E0[0][cc] + E1[0][cc]) + E0[0][cc + 1]) + E1[0][cc + 1]) * 0.25f;
+                        } else {
+                            float x = E0[0][cc] + E0[0][cc + 1];
+                            x = x + E0[1][cc];
+                            x = x + E0[1][cc + 1];
+                            x = x + E1[0][cc];
+                            x = x + E1[0][cc + 1];
+                            x = x + E1[1][cc];
+                            x = x + E1[1][cc + 1];
+                            t[c] = x * 0.125f;
+                        }
+                    }
+                }
+                v.x += t[0];
+                v.y += t[1];
+                v.z += t[2];
+                v.w += t[3];
+            }
+        }
+        return v;
+    };
+    int have_hi = 0;
+    if constexpr (PRO) {
+        const int lo = (a0 - 2 - ((a0 - 2) & 1)) / 2; /* floor((a0-2)/2) */
+        float buf[2];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            coarse_fetch(lo + c, buf);
+            coarse_put(lo + c, buf);
+        }
+        have_hi = lo + 2;
+        __syncthreads();
+    }
+    float4 in_m = load_in(a0 - 2), in_c = load_in(a0 - 1), s_m = zero, s_c = zero, d2 = zero, d3 = zero;
     float4 o_m = zero, o_c = zero;
     double acc = 0.;
     s1b[r][lane] = zero;
     if constexpr (NORM)
         s2b[r][lane] = zero;
     for (int a = a0; a <= a1; a++) {
-        const float4 in_p = load(vin, a);
+        const float4 in_p = load_in(a);
         const float4 d1 = load(d, a - 1);
+        float cbuf[2];
+        bool stage_new = false;
+        if constexpr (PRO) { /* plane a+1 needs coarse planes up to ceil((a+1)/2) */
+            stage_new = (a + 2) / 2 > have_hi && a + 1 >= 0; /* a+1 >= 0: (a+2)/2 == ceil((a+1)/2) */
+            if (stage_new)
+                coarse_fetch(have_hi + 1, cbuf);
+        }
         inp[r][lane] = in_c;
         __syncthreads();
+        if constexpr (PRO) {
+            if (stage_new) {
+                coarse_put(have_hi + 1, cbuf);
+                have_hi++;
+            }
+        }
         const float4 ijm = inp[rm][lane], ijp = inp[rp][lane];   /* input plane a-1 */
         const float4 sjm = s1b[rm][lane], sjp = s1b[rp][lane];   /* sweep-1 plane a-2, published one step ago */
         float4 ojm = zero, ojp = zero;
@@ -723,10 +835,13 @@ static int chunk_for(int planes, long long blocks_per_plane, long long want = 40
     return chunk;
 }
 
+static void e_prolong(mg3d32_ctx *ctx, int level);
+
 /* `iters` sweeps.  norm_slot >= 0: the caller wants ||d - A u|| of the result in sumsq[norm_slot]; returns true when
  * the last launch delivered it (paired sweep with the residual as third stage), false when a residual launch
- * still has to follow. */
-static bool e_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot = -1)
+ * still has to follow.  prolong_first: u += P(u of the next coarser level) before the first sweep (mg_3d.h:1331),
+ * folded into the first paired launch when there is one. */
+static bool e_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot = -1, bool prolong_first = false)
 {
     Level32 &l = ctx->lv[level];
     const int gx = ((l.g.nk + 3) / 4 + 63) / 64, gy = (l.g.nj + 3) / 4;
@@ -740,26 +855,39 @@ static bool e_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot = -1)
         l.f[MG3D_U] = l.alt;
         l.alt = t;
     };
-    if (!no_pairs && l.g.N >= 33) { /* sweeps in pairs: one pass over HBM for two */
+    const bool pairs = !no_pairs && l.g.N >= 33 && iters >= 2;
+    if (prolong_first && !(pairs && !no_fuse))
+        e_prolong(ctx, level);
+    if (pairs) { /* sweeps in pairs: one pass over HBM for two */
         const int px = (l.g.nk + J2_OUT_COLS - 1) / J2_OUT_COLS;
         for (; it + 2 <= iters; it += 2) {
             const bool with_norm = norm_slot >= 0 && !no_fuse && it + 2 == iters;
+            const bool with_pro = prolong_first && !no_fuse && it == 0;
             const int py = (l.g.nj + (with_norm ? J2N_OUT_ROWS : J2_OUT_ROWS) - 1) / (with_norm ? J2N_OUT_ROWS : J2_OUT_ROWS);
             int ch = 128;
             while (ch > 8 && (long long)px * py * ((l.g.ni + ch - 1) / ch) < 1024)
                 ch /= 2;
             while (with_norm && (long long)px * py * ((l.g.ni + ch - 1) / ch) > MG3D_MAX_PARTIALS)
                 ch *= 2;
-            const dim3 grid(px, py, (l.g.ni + ch - 1) / ch);
+            const dim3 grid(px, py, (l.g.ni + ch - 1) / ch), block(64, J2_ROWS, 1);
+            const Geom gc = with_pro ? ctx->lv[level - 1].g : l.g;
+            const float *ec = with_pro ? ctx->lv[level - 1].f[MG3D_U] : nullptr;
+            double *part = with_norm ? ctx->partials : nullptr;
+#define J2_LAUNCH(NORM, PRO)                                                                                       \
+    hipLaunchKernelGGL((jacobi32x2_kernel<NORM, PRO>), grid, block, 0, ctx->stream, l.g, l.f[MG3D_U], l.f[MG3D_D], \
+                       l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, l.invHsq, part, ch, gc, ec)
+            if (with_norm && with_pro)
+                J2_LAUNCH(true, true);
+            else if (with_norm)
+                J2_LAUNCH(true, false);
+            else if (with_pro)
+                J2_LAUNCH(false, true);
+            else
+                J2_LAUNCH(false, false);
+#undef J2_LAUNCH
             if (with_norm) {
-                hipLaunchKernelGGL(jacobi32x2_kernel<true>, grid, dim3(64, J2_ROWS, 1), 0, ctx->stream, l.g, l.f[MG3D_U],
-                                   l.f[MG3D_D], l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, l.invHsq, ctx->partials, ch);
                 k_fold(ctx->partials, (int)(grid.x * grid.y * grid.z), ctx->sumsq + norm_slot, ctx->stream);
                 normed = true;
-            } else {
-                hipLaunchKernelGGL(jacobi32x2_kernel<false>, grid, dim3(64, J2_ROWS, 1), 0, ctx->stream, l.g,
-                                   l.f[MG3D_U], l.f[MG3D_D], l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, l.invHsq,
-                                   (double *)nullptr, ch);
             }
             swap();
         }
@@ -862,10 +990,11 @@ static int e_vcycle(mg3d32_ctx *ctx, int q, int slot)
     Level32 &lc = ctx->lv[q - 1];
     (void)hipMemsetAsync(lc.f[MG3D_U], 0, lc.elems * sizeof(float), ctx->stream); /* :1258 */
     CHK(e_vcycle(ctx, q - 1, ctx->sumsq_slots - 1));    /* :1321 */
-    e_prolong(ctx, q);                                  /* :1331 */
-    /* :1341 + :1354; below the top level the reference drops the norm (:1320), so it is not formed there */
+    /* :1331 + :1341 + :1354; below the top level the reference drops the norm (:1320), so it is not formed there */
     const bool top = q == ctx->L - 1;
-    if (!e_jacobi(ctx, q, ctx->iters, top ? slot : -1) && top)
+    if (ctx->iters == 0)
+        e_prolong(ctx, q);
+    if (!e_jacobi(ctx, q, ctx->iters, top ? slot : -1, ctx->iters > 0) && top)
         e_residual(ctx, q, false, slot);
     return MG3D_OK;
 }
