@@ -118,6 +118,47 @@ def run_cpu_baseline(args):
         return {"value": None, "unit": "V-cycles/s", "cores": cores, "kind": "port", "sample": f"failed: {e}"}
 
 
+def f32_line(args):
+    """One JSON line for the fp32 / damped-Jacobi / F-cycle variant (1 GPU).  Not the headline metric."""
+    import torch
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible (the product has no CPU path)")
+    import multigrid_parallel_amd as M
+    c, nu = args.coarse, args.nu
+    L = args.levels if args.levels != 7 else 8
+    N = (c - 1) * (1 << (L - 1)) + 1
+    alg = sum((3 * 2 * nu + 8) * ((c - 1) * (1 << l) + 1) ** 3 * 4 + 3 * ((c - 1) * (1 << (l - 1)) + 1) ** 3 * 4
+              for l in range(1, L)) + (c ** 6 + 2 * c ** 3) * 8
+    with M.Solver32(c, L, nu) as s:
+        s.setup_test_problem(fmg=False)
+        s.vcycles(args.warmup)
+        s.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        norms = s.vcycles(args.steps)
+        s.sync()
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t0) / args.steps
+        t0 = time.perf_counter()
+        s.setup_test_problem(fmg=True)
+        s.sync()
+        t_fmg = time.perf_counter() - t0
+        after = s.vcycles(1)
+    print(json.dumps({
+        "metric": f"V-cycles/sec, {N}^3 Poisson, fp32, damped-Jacobi V({nu},{nu}) after an F-cycle start (parity unpinned)",
+        "value": 1.0 / per, "unit": "V-cycles/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": per * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{N}^3 Poisson (args {c} {L} {nu}), Dirichlet x^2-2y^2+z^2, omega 6/7, device-resident",
+                   "coarse_pts": c, "levels": L, "smooth_iters": nu, "parallelism": "1 GPU"},
+        "fcycle_start_ms": t_fmg * 1e3, "first_norm": float(norms[0]), "last_norm": float(norms[-1]),
+        "norm_after_fcycle_start": float(after[0]),
+        "roofline": {"bound": "hbm", "kernel": "whole V-cycle (algorithmic bytes of SURVEY 8(d), w = 4)",
+                     "achieved": alg / per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg / per / 1e9 / HBM_PEAK_GBS, "traffic": None},
+        "cpu_baseline": None}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,9 +172,14 @@ def main():
     ap.add_argument("--cpu-port", action="store_true", help="time oracle/ (port) even if oracle/_ref exists")
     ap.add_argument("--cpu-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--breakdown", action="store_true", help="print the per-level stage table to stderr")
+    ap.add_argument("--f32", action="store_true",
+                    help="BASELINE configs[4] on one GPU instead of the headline: fp32, damped Jacobi, F-cycle start "
+                         "(parity unpinned); default size 9 8 2 = 1025^3")
     args = ap.parse_args()
     if args.cpu_child:
         return cpu_child(args)
+    if args.f32:
+        return f32_line(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
