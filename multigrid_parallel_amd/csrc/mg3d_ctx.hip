@@ -513,6 +513,13 @@ static int read_norm(mg3d_ctx *ctx, int slot, double *norm)
     return MG3D_OK;
 }
 
+/* post-smoothing of 4 passes + norm as 2 + 2 passes (see enqueue_smooth_residual); MG3D_SPLIT22=0 keeps 4 + 0 */
+static bool split_up_leg(int iters, int want_res)
+{
+    static const bool off = getenv("MG3D_SPLIT22") && getenv("MG3D_SPLIT22")[0] == '0';
+    return !off && 2 * iters == 4 && want_res == 1;
+}
+
 /* iters x (two colour passes), optionally followed by the residual of the result.
  * Fused path: chunks of 4 (or 2) passes per launch, each launch reading u and writing the
  * alternate buffer; the residual rides on the last launch.  want_res: 0 none, 1 norm only,
@@ -536,7 +543,13 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
         int passes = 2 * iters;
         bool done_res = want_res == 0;
         while (passes > 0 || !done_res) {
-            const int S = passes >= 4 ? 4 : passes; /* 4, 2 or 0 */
+            /* Where the norm is wanted behind FOUR post-smoothing passes (the top level of a V(2,2) cycle) the stage
+             * runs as 2 + 2 passes: the first launch takes the prolongation into its loads (the 2-pass shape has the
+             * registers for it: 0.77 ms against 0.74 ms without), the second one the residual norm (0.90 ms) --
+             * 1.67 ms instead of 0.56 (prolongation) + 0.82 (4 passes) + 0.47 (norm).  Below the top level no norm
+             * is formed and prolongation + 4 passes in two launches stays cheaper. */
+            const bool sp = split_up_leg(iters, want_res);
+            const int S = (sp && post && passes >= 2) ? 2 : passes >= 4 ? 4 : passes; /* 4, 2 or 0 */
             const bool last = passes - S == 0;
             /* the residual rides on a 2-pass launch; behind 4 passes it gets its own launch (the 5-stage
              * window leaves too few registers for a tile with a useful interior: measured 1.9 ms fused
@@ -586,13 +599,17 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
 /* can the prolongation ride on the first smoothing launch?  (needs a smoothing-only first launch) */
 static bool pro_fusable(const mg3d_ctx *ctx, int iters, int want_res)
 {
-    /* Opt-in (MG3D_PRO_FUSE=1): bit-identical, but measured SLOWER on MI355X at 513^3 -- the 4-pass sweep
-     * already uses 249 VGPRs, the prologue spills 44 dwords and the launch takes 1.48 ms against
-     * 0.85 ms (sweep) + 0.56 ms (separate prolongation kernel). */
+    /* On a 4-pass first launch it is opt-in (MG3D_PRO_FUSE=1): bit-identical, but measured SLOWER on MI355X at 513^3 --
+     * the 4-pass sweep already uses 249 VGPRs, the prologue spills 44 dwords and the launch takes 1.48 ms against
+     * 0.85 ms (sweep) + 0.56 ms (separate prolongation kernel).  The 2-pass first launch of a split stage takes it
+     * almost for free. */
     static const bool on = getenv("MG3D_PRO_FUSE") && getenv("MG3D_PRO_FUSE")[0] == '1';
-    if (!on || !ctx->fused || iters < 1)
+    if (!ctx->fused || iters < 1)
         return false;
-    const int first = 2 * iters >= 4 ? 4 : 2;
+    const bool sp = split_up_leg(iters, want_res);
+    if (!on && !sp)
+        return false;
+    const int first = (2 * iters >= 4 && !sp) ? 4 : 2;
     const bool first_has_res = want_res != 0 && first == 2 && 2 * iters == 2;
     return !first_has_res;
 }

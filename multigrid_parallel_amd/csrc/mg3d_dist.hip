@@ -575,16 +575,31 @@ struct RestrictTarget { /* where a rank's restricted residual goes: coarse geome
  * residual (want_res 2: r stored or restricted on the fly into tgt[], 1: norm only, over OWNED planes, into
  * the rank's coarse->sumsq[0]).  Same launch policy as the single-domain path.  On entry the halos of u and
  * d on this level are exact (H planes); nothing is exchanged in here. */
+/* the top level's post-smoothing of a V(2,2) cycle runs as 2 + 2 passes: prolongation folded into the first launch,
+ * the norm into the second (same policy and reasons as the single-domain path, csrc/mg3d_ctx.hip) */
+static bool dist_split_up_leg(const mg3d_dist *D, int post, int want_res)
+{
+    static const bool off = getenv("MG3D_SPLIT22") && getenv("MG3D_SPLIT22")[0] == '0';
+    return !off && post && 2 * D->nu == 4 && want_res == 1;
+}
+
+struct ProlongSource { /* per local rank: the coarse correction a split up-leg folds into its first launch */
+    const Geom *gc;
+    const double *ec;
+};
+
 static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const RestrictTarget *tgt,
                         bool zero_in = false /* u is identically zero: the first launch does not read it */,
-                        bool refresh_u = false /* start the exchange of the u halos (planes 2..H) as soon as u is final */)
+                        bool refresh_u = false /* start the exchange of the u halos (planes 2..H) as soon as u is final */,
+                        const ProlongSource *pro = nullptr)
 {
     hipStream_t s = D->stream;
     const int c1 = post ? 0 : 1;
     int passes = 2 * D->nu;
     bool done_res = want_res == 0, first = true;
+    const bool sp = dist_split_up_leg(D, post, want_res);
     while (passes > 0 || !done_res) {
-        const int S = passes >= 4 ? 4 : passes;
+        const int S = (sp && passes >= 2) ? 2 : passes >= 4 ? 4 : passes;
         const bool last = passes - S == 0;
         const bool res = last && want_res != 0 && S != 4;
         if (S == 0 && refresh_u) { /* u is final; the pure residual launch below reads owned +-1 only */
@@ -619,7 +634,8 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
                                    (res && want_res == 1) ? cx->partials : nullptr, /* the pre-smoothing norm is dropped (:1294) */
                                    MG3D_MAX_PARTIALS, lv.h, S, c1, res, s, sl.own_lo, sl.own_hi,
                                    rst ? tgt[ri].gc : nullptr, rst ? tgt[ri].dc : nullptr, rst ? tgt[ri].lo : -1,
-                                   rst ? tgt[ri].hi : -1, nullptr, nullptr, w_lo, w_hi);
+                                   rst ? tgt[ri].hi : -1, (pro && first) ? pro[ri].gc : nullptr,
+                                   (pro && first) ? pro[ri].ec : nullptr, w_lo, w_hi);
             if (res && want_res == 1)
                 k_fold(cx->partials, np, cx->sumsq, s);
         }
@@ -706,21 +722,22 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
         if (l - 1 >= ld)
             CHK(exchange_halo(D, MG3D_U, l - 1, s));
         CHK(await_u(D, l));
-        for (auto &R : D->rs) {
+        const int want = l == L - 1 ? 1 : 0;
+        const bool fold = dist_split_up_leg(D, 1, want);
+        std::vector<ProlongSource> pro(D->rs.size());
+        for (size_t ri = 0; ri < D->rs.size(); ri++) {
+            RankState &R = D->rs[ri];
             SlabLevel &sl = SL(D, R, l);
-            if (l - 1 >= ld) {
-                SlabLevel &sc = SL(D, R, l - 1);
-                k_prolong(sc.lv.g, sc.lv.f[MG3D_U], sl.lv.g, sl.lv.f[MG3D_U], s, 0, sl.lv.g.ni);
-            } else {
-                Level &lc = R.coarse->lv[ld - 1];
+            Level &lc = l - 1 >= ld ? SL(D, R, l - 1).lv : R.coarse->lv[ld - 1];
+            pro[ri] = ProlongSource{&lc.g, lc.f[MG3D_U]};
+            if (!fold)
                 k_prolong(lc.g, lc.f[MG3D_U], sl.lv.g, sl.lv.f[MG3D_U], s, 0, sl.lv.g.ni);
-            }
         }
         /* :1341 (+ :1354 at the top level): all H halo planes of u are exact here, the post-smoother uses up
          * 2*nu of them.  The next cycle's pre-smoother wants fresh halos on the finest u: that exchange starts
          * underneath the norm kernel, which reads the first halo plane on either side -- just produced
          * exactly by the post-smoother, so the exchange leaves that plane alone. */
-        CHK(stage_smooth(D, l, 1, l == L - 1 ? 1 : 0, nullptr, false, l == L - 1));
+        CHK(stage_smooth(D, l, 1, want, nullptr, false, l == L - 1, fold ? pro.data() : nullptr));
     }
     CHK(reduce_norm(D, slot));
     hipError_t e = hipGetLastError();
