@@ -534,7 +534,11 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
     /* a thin plane range (an i-slab of a multi-GPU run): if some exact division fits in ONE round of blocks
      * and clearly beats the multi-round choice above, take it (68 planes of 513^2: 2 chunks of 34) */
     if (blocks(CI) > 256) {
-        const double cur = (double)blocks(CI) / 256.0 * (CI + ovh);
+        /* one 512-thread block per CU (every shape needs > 128 VGPRs): up to two rounds are counted whole (380
+         * blocks take as long as 512), beyond that the tail overlaps well enough for the fractional figure */
+        static const int whole = getenv("MG3D_SLAB_ROUNDS") ? atoi(getenv("MG3D_SLAB_ROUNDS")) : 1;
+        const double cur = ((whole == 2 || (whole == 1 && blocks(CI) <= 512)) ? (double)((blocks(CI) + 255) / 256)
+                                                                             : (double)blocks(CI) / 256.0) * (CI + ovh);
         for (int k = 1; k <= 8; k++) {
             const int ci = (nout + k - 1) / k;
             if (ci >= 2 && blocks(ci) <= 256 && (double)(ci + ovh) < 0.9 * cur) {
