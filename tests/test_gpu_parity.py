@@ -182,6 +182,27 @@ def test_lu_solve_dense_random_matrix():
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,bw", [(64, 5), (65, 63), (200, 64), (300, 65), (257, 100), (511, 128), (640, 127), (130, 129)])
+def test_lu_solve_random_banded_matrix(n, bw):
+    """Generic banded factors (not the Poisson operator): unknown counts that are not multiples of the 64-step
+    chunk, half bandwidths on either side of the one-/two-rows-per-lane and the single-wave/block-kernel boundaries
+    (64, 128).  Asymmetric band content, random right-hand side with a few exact zeros."""
+    rng = np.random.default_rng(n * 131 + bw)
+    A = np.zeros((n, n))
+    for i in range(n):
+        lo, hi = max(0, i - bw), min(n, i + bw + 1)
+        A[i, lo:hi] = rng.uniform(-1, 1, hi - lo)
+        A[i, i] = 2.0 * bw + 1.0 + rng.uniform(0, 1)
+    LU = A.reshape(-1).copy()
+    O.lib().orc_lu_factor(O.P(LU), n)
+    b = rng.uniform(-1, 1, n)
+    b[rng.random(n) < 0.1] = 0.0
+    want, got = np.zeros(n), np.zeros(n)
+    O.lib().orc_lu_solve(O.P(LU), n, O.P(b), O.P(want))
+    check(M.lib().mg3d_host_lu_solve(P(LU), n, P(b), P(got)))
+    assert np.array_equal(got, want)
+
+
 # ------------------------------------------------------------------ whole V-cycles
 @pytest.mark.parametrize("c,L,nu", [(3, 3, 1), (3, 5, 2), (5, 3, 3), (9, 2, 2), (5, 5, 2), (9, 5, 2), (3, 2, 0)])
 def test_vcycle_history_and_solution_bit_exact(c, L, nu):
