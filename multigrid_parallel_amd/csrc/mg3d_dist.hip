@@ -323,7 +323,10 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
     DCHK(hipHostMalloc(&D->h_norms, sizeof(double) * D->norm_slots));
     DCHK(hipStreamSynchronize(D->stream));
 #undef DCHK
-    if (!D->loopback && nranks > 1) {
+    /* MG3D_FORCE_COMM=1: build the communicators for a single rank too (lets a one-GPU box exercise the unique-id
+     * marshalling, ncclCommInitRank and ncclCommSplit of the multi-process path) */
+    static const bool force_comm = getenv("MG3D_FORCE_COMM") && getenv("MG3D_FORCE_COMM")[0] == '1';
+    if (!D->loopback && (nranks > 1 || force_comm)) {
         ncclUniqueId id;
         memcpy(&id, unique_id, sizeof id);
         ncclResult_t e = ncclCommInitRank(&D->comm, nranks, id, rank);
@@ -507,7 +510,7 @@ static int allgather_coarse_rhs(mg3d_dist *D)
 {
     hipStream_t s = D->stream;
     const int lc = D->ld - 1;
-    if (D->P == 1)
+    if (D->P == 1 && !D->have_comm) /* a forced single-rank communicator still runs the collective (self-test) */
         return MG3D_OK;
     auto range = [&](int r, int *lo, int *hi) {
         int flo, fhi;
@@ -556,7 +559,7 @@ static int reduce_norm(mg3d_dist *D, int slot)
         return MG3D_OK;
     }
     RankState &R = D->rs[0];
-    if (D->P > 1)
+    if (D->have_comm)
         NCCLCHK(ncclAllGather(R.coarse->sumsq, R.gather, 1, ncclDouble, D->comm, s));
     else
         HIPCHK(hipMemcpyAsync(R.gather, R.coarse->sumsq, sizeof(double), hipMemcpyDeviceToDevice, s));

@@ -69,6 +69,21 @@ def test_single_rank_rccl_communicator():
     np.testing.assert_allclose(norms, want_norms, rtol=1e-11)
 
 
+def test_single_rank_builds_real_communicators(monkeypatch):
+    """MG3D_FORCE_COMM=1: the 128-byte unique id travels through ctypes into ncclCommInitRank, the second
+    communicator comes from ncclCommSplit, both are destroyed again -- everything of the multi-process set-up that
+    one GPU can run (RCCL refuses two ranks on one device)."""
+    monkeypatch.setenv("MG3D_FORCE_COMM", "1")
+    uid = M.DistSolver.unique_id()
+    assert len(uid) == 128 and any(uid)
+    want_norms, want_u = single(5, 4, 2, 3)
+    with M.DistSolver(5, 4, 2, rank=0, nranks=1, unique_id=uid) as d:
+        d.setup_test_problem()
+        norms = d.vcycles(3)
+        assert np.array_equal(d.download(MG3D_U, 3), want_u)
+    np.testing.assert_allclose(norms, want_norms, rtol=1e-11)
+
+
 def test_overlap_and_sequential_exchange_agree(monkeypatch):
     """MG3D_NO_OVERLAP=1 keeps every halo exchange on the compute stream; by default the large u exchanges run on
     a second stream underneath the coarser levels and the norm kernel."""
