@@ -142,6 +142,7 @@ struct mg3d_dist {
     double *d_norms; /* device: squared norms per cycle */
     int norm_slots;
     std::vector<double> spacing; /* per level */
+    double *selftest; /* MG3D_FORCE_COMM=1 on one rank: H planes of the finest level, target of the self-addressed receives */
 };
 
 static SlabLevel &SL(mg3d_dist *D, RankState &R, int l) { return R.dl[l - D->ld]; }
@@ -202,6 +203,8 @@ extern "C" int mg3d_dist_destroy(mg3d_dist *D)
     for (auto &R : D->rs)
         if (R.coarse)
             mg3d_ctx_destroy(R.coarse);
+    if (D->selftest)
+        (void)hipFree(D->selftest);
     if (D->d_norms)
         (void)hipFree(D->d_norms);
     if (D->h_norms)
@@ -233,6 +236,7 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
     D->loopback = unique_id == nullptr;
     D->device = device;
     D->have_comm = D->have_comm2 = false;
+    D->selftest = nullptr;
     D->stream = nullptr;
     D->h_norms = D->d_norms = nullptr;
     D->comm_stream = nullptr;
@@ -336,6 +340,11 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
             return rc;
         }
         D->have_comm = true;
+        if (nranks == 1) { /* forced: scratch for the self-addressed exchanges */
+            const Geom &gt = D->rs[0].dl.back().lv.g;
+            if (hipMalloc(&D->selftest, (size_t)D->H * gt.plane * sizeof(double)) != hipSuccess)
+                D->selftest = nullptr;
+        }
         /* a second communicator for the communication stream: two RCCL operations may only be in flight
          * together on different communicators.  Without it the exchanges stay on the compute stream. */
         if (D->overlap) {
@@ -446,8 +455,22 @@ extern "C" int mg3d_dist_sync(mg3d_dist *D)
 static int exchange_halo(mg3d_dist *D, int field, int l, hipStream_t s, int skip = 0)
 {
     const int H = D->H, n = D->H - skip;
-    if (D->P == 1 || n <= 0)
+    if (n <= 0)
         return MG3D_OK;
+    if (D->P == 1) {
+        /* forced single-rank communicators (MG3D_FORCE_COMM=1): the same grouped send/receive, addressed to
+         * itself and landing in a scratch buffer -- a one-GPU self-test of the calls, streams and events */
+        if (D->have_comm && D->selftest) {
+            SlabLevel &a = SL(D, D->rs[0], l);
+            const size_t cnt = (size_t)n * a.lv.g.plane;
+            ncclComm_t comm = (s == D->comm_stream && D->have_comm2) ? D->comm2 : D->comm;
+            NCCLCHK(ncclGroupStart());
+            NCCLCHK(ncclSend(a.lv.f[field] + a.lv.g.plane * (a.own_lo + skip), cnt, ncclDouble, 0, comm, s));
+            NCCLCHK(ncclRecv(D->selftest, cnt, ncclDouble, 0, comm, s));
+            NCCLCHK(ncclGroupEnd());
+        }
+        return MG3D_OK;
+    }
     if (D->loopback) {
         for (int r = 0; r + 1 < D->P; r++) {
             SlabLevel &a = SL(D, D->rs[r], l), &b = SL(D, D->rs[r + 1], l);
@@ -483,7 +506,7 @@ static int exchange_halo(mg3d_dist *D, int field, int l, hipStream_t s, int skip
  * holding the compute stream up; await_u() makes the compute stream wait for the arrival. */
 static int start_u_exchange(mg3d_dist *D, int l, int skip)
 {
-    if (D->P == 1)
+    if (D->P == 1 && !D->selftest)
         return MG3D_OK;
     if (!D->overlap)
         return exchange_halo(D, MG3D_U, l, D->stream, skip);
