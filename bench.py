@@ -196,7 +196,8 @@ def main():
     if "MG3D_BENCH_DEVICE" in os.environ:  # rehearsal of several ranks on one GPU (RCCL permitting)
         local_rank = int(os.environ["MG3D_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("MG3D_BENCH_FORCE_DIST") == "1"  # rehearsal: the N > 1 code path with one rank
+    if world > 1 or (force_dist and "RANK" in os.environ):
         backend = os.environ.get("MG3D_BENCH_TORCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -210,16 +211,17 @@ def main():
     N = (c - 1) * (1 << (L - 1)) + 1
 
     def barrier(obj):
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         obj.sync()
         torch.cuda.synchronize()
 
-    if world > 1:
+    if world > 1 or force_dist:
         # i-slab decomposition: one rank per GPU, the library's own RCCL communicator for the plane
         # exchanges (unique id distributed through torch.distributed), strong scaling of the same problem
         uid = [M.DistSolver.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
+        if dist.is_initialized():
+            dist.broadcast_object_list(uid, src=0)
         solver = M.DistSolver(c, L, nu, rank=rank, nranks=world, unique_id=uid[0], device=local_rank)
         init = solver.setup_test_problem()
         solver.vcycles(args.warmup)
@@ -228,10 +230,11 @@ def main():
         norms = solver.vcycles(args.steps)
         barrier(solver)
         elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if dist.is_initialized():
+            t = torch.tensor([elapsed], dtype=torch.float64,
+                             device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
         if rank == 0:
             alg = algorithmic_bytes_per_cycle(c, L, nu)
             per_step = elapsed / args.steps
@@ -255,7 +258,8 @@ def main():
                              "frac": alg / per_step / 1e9 / (HBM_PEAK_GBS * world), "traffic": None},
                 "cpu_baseline": None}))
         solver.close()
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
         return
 
     solver = M.Solver(c, L, nu)
