@@ -118,6 +118,28 @@ def run_cpu_baseline(args):
         return {"value": None, "unit": "V-cycles/s", "cores": cores, "kind": "port", "sample": f"failed: {e}"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run` (one rank per GPU,
+    rendezvous on 127.0.0.1) as a CHILD process before anything here touches the GPU, relay its output (rank 0
+    prints the JSON line) and exit with its return code."""
+    import socket
+    import torch  # device_count() does not initialise the GPU on this image
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs (one rank per GPU; RCCL refuses two ranks "
+              f"on one device), this box has {have}", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def f32_line(args):
     """One JSON line for the fp32 / damped-Jacobi / F-cycle variant (1 GPU).  Not the headline metric."""
     import torch
@@ -181,13 +203,12 @@ def main():
     if args.f32:
         return f32_line(args)
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)  # plain `python bench.py --gpus N`: become the launcher, one child rank per GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
 
     import torch  # first: libmg3d then shares torch's HIP runtime (same SONAME)
     import torch.distributed as dist
@@ -224,7 +245,7 @@ def main():
             dist.broadcast_object_list(uid, src=0)
         solver = M.DistSolver(c, L, nu, rank=rank, nranks=world, unique_id=uid[0], device=local_rank)
         init = solver.setup_test_problem()
-        solver.vcycles(args.warmup)
+        warm_norms = solver.vcycles(args.warmup)
         barrier(solver)
         t0 = time.perf_counter()
         norms = solver.vcycles(args.steps)
@@ -235,6 +256,16 @@ def main():
                              device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        rccl_ranks, overlap, dev = solver.comm_info()
+        placement = [(rank, dev, torch.cuda.get_device_properties(dev).name)]
+        if dist.is_initialized():
+            gathered = [None] * world
+            dist.all_gather_object(gathered, placement[0])
+            placement = gathered
+        # the reference's own printed history of this problem (SURVEY 6.3, 513^3 `9 7 2`, six printed digits): cycles 4 and 5
+        known = {4: 80775.4, 5: 11126.2} if (c, L, nu) == (9, 7, 2) else {}
+        hist = list(warm_norms) + list(norms)
+        known_ok = all(abs(hist[k - 1] - v) <= 1e-5 * v for k, v in known.items() if k - 1 < len(hist)) if known else None
         if rank == 0:
             alg = algorithmic_bytes_per_cycle(c, L, nu)
             per_step = elapsed / args.steps
@@ -251,6 +282,9 @@ def main():
                 "vcycle_algorithmic_gb": alg / 1e9, "vcycle_algorithmic_gbs": alg / per_step / 1e9,
                 "vcycle_frac_of_hbm_peak": alg / per_step / 1e9 / (HBM_PEAK_GBS * world),
                 "first_norm": float(norms[0]), "last_norm": float(norms[-1]), "initial_rhs_norm": init,
+                "rccl_ranks": rccl_ranks, "halo_overlap": overlap,
+                "ranks": [{"rank": r, "device": d, "name": n} for r, d, n in placement],
+                "history_matches_reference": known_ok,
                 # no per-kernel timers on the slab path: the whole cycle against the aggregate HBM peak (the
                 # per-kernel roofline and the CPU baseline belong to the N = 1 line)
                 "roofline": {"bound": "hbm", "kernel": "whole V-cycle, all ranks (algorithmic bytes of SURVEY 8(d))",

@@ -145,6 +145,9 @@ int mg3d_comm_unique_id(void *out128);
 int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters, double grid_length, int rank, int nranks,
                      const void *unique_id, int device, mg3d_dist **out);
 int mg3d_dist_destroy(mg3d_dist *d);
+/* ranks in the RCCL communicator (ncclCommCount; 0 without one), whether the u exchanges overlap the coarser
+ * levels on a second stream/communicator (MG3D_OVERLAP=1; default off for RCCL), the HIP device in use */
+int mg3d_dist_comm_info(const mg3d_dist *d, int *rccl_ranks, int *overlap, int *device);
 int mg3d_dist_first_level(const mg3d_dist *d); /* lowest distributed level */
 int mg3d_dist_halo(const mg3d_dist *d);        /* halo planes per side */
 int mg3d_dist_build_coarse(mg3d_dist *d, double h_coarse);

@@ -207,12 +207,25 @@ static inline double mg3d_vcycle8_(double **lu_, double **lf_, double **lres_, i
 #define vcycle(...) MG3D_PICK9_(__VA_ARGS__, mg3d_vcycle9_, mg3d_vcycle8_, )(__VA_ARGS__)
 
 /* ---- Solver facade (mg_3d.h:107-144, 275-293, 1412-1467) ----------------------------- */
+/* Every Solver* call except SolverLinSolve goes through here: the device result (if newer) comes back
+ * into the arrays SolverGetDetails handed out, and -- because the caller owns those arrays and may write
+ * grid[] / rhs[] through the raw pointers at any time after such a call (the reference sees such writes,
+ * mg_3d.h:278-279) -- the next SolverLinSolve uploads them again.  Writes between two consecutive
+ * SolverLinSolve calls with no other Solver* call in between are not visible to a call counter: announce
+ * them with SolverMarkHostDirty(), or run with MG3D_SYNC_EVERY_CYCLE=1 (download + upload around every cycle). */
 static inline void mg3d_pull_(void)
 {
     if (mg3d_solver_ctx_ && mg3d_device_newer_) {
         mg3d_die_(mg3d_download(mg3d_solver_ctx_, MG3D_U, numLevels - 1, u[numLevels - 1]), "libmg3d download");
         mg3d_device_newer_ = 0;
     }
+    mg3d_host_newer_ = 1;
+}
+
+/* not in the reference: tells the facade that grid[] / rhs[] were written between two SolverLinSolve calls */
+static inline void SolverMarkHostDirty(void)
+{
+    mg3d_pull_();
 }
 
 static inline void SolverInitialize(int argc, char **argv)
@@ -344,6 +357,7 @@ static inline double SolverGetInitialResidual(void)
 
 static inline void SolverResetTimingInfo(void)
 {
+    mg3d_pull_();
     mg3d_die_(mg3d_timing_reset(mg3d_solver_ctx_), "SolverResetTimingInfo");
     resetTimingInfo(tInfo, numLevels);
 }

@@ -68,6 +68,7 @@ SIGNATURES = {
     "mg3d_dist_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                    C.POINTER(C.c_void_p)]),
     "mg3d_dist_destroy": (C.c_int, [C.c_void_p]),
+    "mg3d_dist_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mg3d_dist_first_level": (C.c_int, [C.c_void_p]),
     "mg3d_dist_halo": (C.c_int, [C.c_void_p]),
     "mg3d_dist_set_keep_residual": (C.c_int, [C.c_void_p, C.c_int]),
@@ -338,6 +339,12 @@ class DistSolver:
         self.h = grid_length / (self.N - 1)
         self.first_level = self.L.mg3d_dist_first_level(self._h)
         self.halo = self.L.mg3d_dist_halo(self._h)
+
+    def comm_info(self):
+        """(ranks in the RCCL communicator, overlap on/off, HIP device)"""
+        n, ov, dev = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(self.L.mg3d_dist_comm_info(self._h, C.byref(n), C.byref(ov), C.byref(dev)))
+        return n.value, bool(ov.value), dev.value
 
     @staticmethod
     def unique_id():

@@ -241,7 +241,17 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
     D->h_norms = D->d_norms = nullptr;
     D->comm_stream = nullptr;
     D->ev_ready = nullptr;
-    D->overlap = !(getenv("MG3D_NO_OVERLAP") && getenv("MG3D_NO_OVERLAP")[0] == '1');
+    /* Overlap of the large u exchanges with the coarser levels (second stream, second communicator).  Loopback:
+     * on by default (plain stream concurrency).  RCCL: OFF by default -- two communicators driven concurrently
+     * from two streams of one device have never run on more than one physical GPU here (one GPU per box), and
+     * RCCL only guarantees progress for that pattern while both of its kernels can be co-resident; until a
+     * multi-GPU run has shown it, every exchange stays on the compute stream with ONE communicator.
+     * MG3D_OVERLAP=1 opts in, MG3D_NO_OVERLAP=1 forces it off (also for loopback). */
+    {
+        const bool off = getenv("MG3D_NO_OVERLAP") && getenv("MG3D_NO_OVERLAP")[0] == '1';
+        const bool on = getenv("MG3D_OVERLAP") && getenv("MG3D_OVERLAP")[0] == '1';
+        D->overlap = !off && (D->loopback || on);
+    }
     if (D->ld >= num_levels) {
         delete D;
         return fail(MG3D_ERR_ARG, "mg3d_dist_create: %d ranks leave no level with >= 8 planes per rank", nranks);
@@ -329,7 +339,7 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
 #undef DCHK
     /* MG3D_FORCE_COMM=1: build the communicators for a single rank too (lets a one-GPU box exercise the unique-id
      * marshalling, ncclCommInitRank and ncclCommSplit of the multi-process path) */
-    static const bool force_comm = getenv("MG3D_FORCE_COMM") && getenv("MG3D_FORCE_COMM")[0] == '1';
+    const bool force_comm = getenv("MG3D_FORCE_COMM") && getenv("MG3D_FORCE_COMM")[0] == '1';
     if (!D->loopback && (nranks > 1 || force_comm)) {
         ncclUniqueId id;
         memcpy(&id, unique_id, sizeof id);
@@ -359,6 +369,22 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
         }
     }
     *out = D;
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_dist_comm_info(const mg3d_dist *D, int *rccl_ranks, int *overlap, int *device)
+{
+    if (!D)
+        return fail(MG3D_ERR_ARG, "mg3d_dist_comm_info: NULL");
+    int n = 0;
+    if (D->have_comm)
+        NCCLCHK(ncclCommCount(D->comm, &n));
+    if (rccl_ranks)
+        *rccl_ranks = n; /* 0: no RCCL communicator (loopback, or one rank) */
+    if (overlap)
+        *overlap = D->overlap ? 1 : 0;
+    if (device)
+        *device = D->device;
     return MG3D_OK;
 }
 

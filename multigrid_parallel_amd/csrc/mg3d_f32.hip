@@ -55,6 +55,9 @@ struct mg3d32_ctx {
     hipStream_t stream;
     double *partials, *sumsq, *h_sumsq;
     int sumsq_slots;
+    /* MG3D_F32_NO_PAIRS=1 / MG3D_F32_NO_FUSE=1, read when the context is created: one launch per sweep / per
+     * operator instead of the paired and fused kernels (same bits; tests/test_gpu_f32.py) */
+    bool no_pairs, no_fuse;
 };
 
 static inline int pitch32(int nk) { return (nk + 31) & ~31; }
@@ -719,6 +722,8 @@ extern "C" int mg3d32_create(int coarse_pts, int num_levels, int smooth_iters, d
     ctx->L = num_levels;
     ctx->iters = smooth_iters;
     ctx->omega = (float)omega;
+    ctx->no_pairs = getenv("MG3D_F32_NO_PAIRS") && getenv("MG3D_F32_NO_PAIRS")[0] == '1';
+    ctx->no_fuse = getenv("MG3D_F32_NO_FUSE") && getenv("MG3D_F32_NO_FUSE")[0] == '1';
     ctx->coarse64 = nullptr;
     ctx->partials = ctx->sumsq = ctx->h_sumsq = nullptr;
     ctx->stream = nullptr;
@@ -848,8 +853,7 @@ static bool e_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot = -1, 
     const int chunk = chunk_for(l.g.ni, (long long)gx * gy);
     int it = 0;
     bool normed = false;
-    static const bool no_pairs = getenv("MG3D_F32_NO_PAIRS") && getenv("MG3D_F32_NO_PAIRS")[0] == '1';
-    static const bool no_fuse = getenv("MG3D_F32_NO_FUSE") && getenv("MG3D_F32_NO_FUSE")[0] == '1';
+    const bool no_pairs = ctx->no_pairs, no_fuse = ctx->no_fuse;
     auto swap = [&]() {
         float *t = l.f[MG3D_U];
         l.f[MG3D_U] = l.alt;
@@ -980,8 +984,7 @@ static int e_vcycle(mg3d32_ctx *ctx, int q, int slot)
     if (q == 0)
         return e_coarse_solve(ctx);
     e_jacobi(ctx, q, ctx->iters);                       /* :1282 */
-    static const bool no_fuse = getenv("MG3D_F32_NO_FUSE") && getenv("MG3D_F32_NO_FUSE")[0] == '1';
-    if (!no_fuse && ctx->lv[q].g.N >= 33) {
+    if (!ctx->no_fuse && ctx->lv[q].g.N >= 33) {
         e_residual_restrict(ctx, q);                    /* :1294 + :1310, r not stored */
     } else {
         e_residual(ctx, q, true, ctx->sumsq_slots - 1); /* :1294 (its norm is dropped) */

@@ -166,6 +166,53 @@ def test_api_surface_driver(tmp_path):
 
 
 @pytest.mark.gpu
+def test_facade_sees_host_writes_between_solves(tmp_path):
+    """tests/c/host_dirty.c: rhs[] and grid[] are changed through the raw pointers of SolverGetDetails after
+    SolverGetResidual / SolverResetTimingInfo / SolverMarkHostDirty; the following cycles must start from those
+    writes, as they do in the reference (mg_3d.h:278-279 hands out the solver's own arrays)."""
+    exe = tmp_path / "host_dirty"
+    subprocess.run(["gcc", "-O2", "-fopenmp", "-I" + os.path.join(ROOT, "include"), "-o", str(exe),
+                    os.path.join(ROOT, "tests", "c", "host_dirty.c"), "-L" + os.path.join(ROOT, "multigrid_parallel_amd", "lib"),
+                    "-Wl,-rpath," + os.path.join(ROOT, "multigrid_parallel_amd", "lib"), "-lmg3d", "-lm"], check=True)
+    r = run([str(exe)], tmp_path, 2)
+    assert r.returncode == 0, r.stderr
+    val = lambda tag: [float(m) for m in re.findall(rf"^{tag} (\S+)$", r.stdout, flags=re.M)]
+    lib = O.lib()
+    lib.orc_set_threads(1)
+    c, L, nu = 5, 3, 2
+    H = O.Hierarchy(c, L)
+    N, h = H.N[-1], 1.0 / (H.N[-1] - 1)
+    LU = np.zeros(c ** 6)
+    lib.orc_coarse_matrix(O.P(LU), c, h * (1 << (L - 1)))
+    lib.orc_lu_factor(O.P(LU), c ** 3)
+    lib.orc_fill_boundary(O.P(H.d[-1]), N, h)
+    lib.orc_fill_boundary(O.P(H.u[-1]), N, h)
+    cyc = lambda: lib.orc_vcycle(H.ptrs(H.u), H.ptrs(H.d), H.ptrs(H.r), h, L - 1, L, nu, N, O.P(LU))
+    A = [cyc() for _ in range(3)]
+    R = lib.orc_residual(O.P(H.u[-1]), O.P(H.d[-1]), N, h, None)
+    mid = (N * N + N + 1) * (N // 2)
+    keep = [a.copy() for a in H.u], [a.copy() for a in H.d]
+    unchanged = cyc()  # what the fourth cycle would return had the caller not written anything
+    for dst, src in zip(H.u + H.d, keep[0] + keep[1]):
+        dst[:] = src
+    H.d[-1][mid] = 250.0
+    H.u[-1][mid + 1] += 0.125
+    B = [cyc() for _ in range(3)]
+    H.d[-1][mid - N] = -125.0
+    Cc = [cyc() for _ in range(2)]
+    H.u[-1][mid - 1] -= 0.25
+    D = [cyc()]
+    assert val("A") == pytest.approx(A, rel=1e-13) and val("R") == pytest.approx([R], rel=1e-13)
+    assert val("B") == pytest.approx(B, rel=1e-13)
+    assert abs(B[0] - unchanged) > 1e-3 * unchanged  # the writes really entered the solve
+    assert val("C") == pytest.approx(Cc, rel=1e-13) and val("D") == pytest.approx(D, rel=1e-13)
+    su = 0.0
+    for p in range(N ** 3):
+        su += H.u[-1][p] * (1 + p % 13)
+    assert val("U")[0] == su
+
+
+@pytest.mark.gpu
 def test_reference_test_mg_3d_129_cubed(tmp_path):
     """BASELINE configs[1]: `9 5 2` = 129^3, V(2,2), through the unchanged reference driver."""
     if not os.path.exists(BIN1):

@@ -74,14 +74,21 @@ def test_single_rank_builds_real_communicators(monkeypatch):
     communicator comes from ncclCommSplit, both are destroyed again -- everything of the multi-process set-up that
     one GPU can run (RCCL refuses two ranks on one device)."""
     monkeypatch.setenv("MG3D_FORCE_COMM", "1")
+    monkeypatch.setenv("MG3D_OVERLAP", "1")  # opt-in for the RCCL transport: second stream + ncclCommSplit communicator
     uid = M.DistSolver.unique_id()
     assert len(uid) == 128 and any(uid)
     want_norms, want_u = single(5, 4, 2, 3)
     with M.DistSolver(5, 4, 2, rank=0, nranks=1, unique_id=uid) as d:
+        assert d.comm_info()[:2] == (1, True)  # ncclCommCount of the real communicator; overlap opted in
         d.setup_test_problem()
         norms = d.vcycles(3)
         assert np.array_equal(d.download(MG3D_U, 3), want_u)
     np.testing.assert_allclose(norms, want_norms, rtol=1e-11)
+    monkeypatch.delenv("MG3D_OVERLAP")
+    with M.DistSolver(5, 4, 2, rank=0, nranks=1, unique_id=uid) as d:  # the RCCL default: one communicator, no overlap
+        assert d.comm_info()[:2] == (1, False)
+        d.setup_test_problem()
+        assert np.array_equal(d.vcycles(3), norms)
 
 
 def test_overlap_and_sequential_exchange_agree(monkeypatch):
