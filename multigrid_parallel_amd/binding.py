@@ -22,7 +22,8 @@ class Mg3dError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libmg3d.so")
+    # MG3D_LIB_PATH: an alternative build of the same library (A/B measurements of kernel variants on one box)
+    return os.environ.get("MG3D_LIB_PATH") or os.path.join(_HERE, "lib", "libmg3d.so")
 
 
 _lib = None
@@ -125,6 +126,9 @@ def lib():
             raise Mg3dError(2, f"{path} not built; run __graft_entry__.build() (there is no CPU fallback)")
         L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name, None)
+            if fn is None and os.environ.get("MG3D_LIB_PATH"):
+                continue  # an older build used as an A/B reference may lack newer entry points
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -33,6 +33,11 @@ struct mg3d_ctx {
     int sumsq_slots;
     double *h_sumsq;  /* pinned mirror */
     bool keep_r; /* materialise r on every level (reference-visible array) instead of restricting it on the fly */
+    /* The faces of a coarse right-hand side are an injection of the fine residual's faces (mg_3d.h:879-958), and
+     * calculateResidual never writes those (:824-825): they only change when somebody outside the cycle writes r of
+     * level l or d of level l-1.  faces_dirty[l] says the injection l -> l-1 has to be redone (set at creation, by
+     * upload / zero of those fields); faces_always[l] after a raw device pointer to one of them was handed out. */
+    std::vector<char> faces_dirty, faces_always;
     bool fused; /* fused sweep kernel (default) or one launch per colour pass (MG3D_NO_FUSE=1) */
     int timing; /* 0 off, 1 every level, 2 finest level only */
     std::vector<StageTimer> timers; /* [L][MG3D_NUM_STAGES] */
@@ -46,6 +51,8 @@ struct mg3d_ctx {
     std::vector<hipEvent_t> event_pool;
 };
 
+/* field `field` of `level` was written from outside the cycle (see faces_dirty) */
+void mg3d_ctx_touched(mg3d_ctx *ctx, int field, int level, bool raw_pointer = false);
 /* records a failure text for mg3d_last_error() and returns `code` */
 int mg3d_fail(int code, const char *fmt, ...);
 /* enqueue one V-cycle from level q of a (single-domain) context; squared norm of level q to sumsq[slot] */

@@ -201,6 +201,8 @@ static mg3d_ctx *ctx_new(int L, int iters)
     ctx->lv.resize(L);
     for (auto &l : ctx->lv)
         l.f[0] = l.f[1] = l.f[2] = l.alt = nullptr;
+    ctx->faces_dirty.assign(L, 1);
+    ctx->faces_always.assign(L, 0);
     ctx->fused = true;
     ctx->keep_r = false;
     if (const char *e = getenv("MG3D_KEEP_R"))
@@ -208,6 +210,16 @@ static mg3d_ctx *ctx_new(int L, int iters)
     if (const char *e = getenv("MG3D_NO_FUSE"))
         ctx->fused = !(e[0] == '1');
     return ctx;
+}
+
+void mg3d_ctx_touched(mg3d_ctx *ctx, int field, int level, bool raw_pointer)
+{
+    const int l = field == MG3D_R ? level : field == MG3D_D ? level + 1 : -1;
+    if (l >= 1 && l < ctx->L) {
+        ctx->faces_dirty[l] = 1;
+        if (raw_pointer)
+            ctx->faces_always[l] = 1;
+    }
 }
 
 static int ctx_create_sizes(const int *n_per_level, const double *h_per_level, int L, int iters, mg3d_ctx **out)
@@ -445,6 +457,7 @@ extern "C" int mg3d_upload(mg3d_ctx *ctx, int field, int level, const double *ho
     HIPCHK(hipMemcpy2DAsync(l.f[field], l.g.pitch * sizeof(double), host, N * sizeof(double), N * sizeof(double),
                             (size_t)N * N, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    mg3d_ctx_touched(ctx, field, level);
     return MG3D_OK;
 }
 
@@ -466,6 +479,7 @@ extern "C" int mg3d_zero(mg3d_ctx *ctx, int field, int level)
     CHK(check_field_level(ctx, field, level, "mg3d_zero"));
     const Level &l = ctx->lv[level];
     HIPCHK(hipMemsetAsync(l.f[field], 0, l.elems * sizeof(double), ctx->stream));
+    mg3d_ctx_touched(ctx, field, level);
     return MG3D_OK;
 }
 
@@ -483,6 +497,7 @@ extern "C" int mg3d_device_view(mg3d_ctx *ctx, int field, int level, void **dev_
 {
     CHK(check_field_level(ctx, field, level, "mg3d_device_view"));
     const Level &l = ctx->lv[level];
+    mg3d_ctx_touched(ctx, field, level, true);
     if (dev_ptr)
         *dev_ptr = l.f[field];
     if (pitch_doubles)
@@ -524,7 +539,7 @@ static bool split_up_leg(int iters, int want_res)
  * Fused path: chunks of 4 (or 2) passes per launch, each launch reading u and writing the
  * alternate buffer; the residual rides on the last launch.  want_res: 0 none, 1 norm only,
  * 2 store r (+ norm).  The squared norm goes to sumsq[slot]. */
-static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters, int want_res, int slot,
+static int enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters, int want_res, int slot,
                                     Level *coarse = nullptr, const Level *pro = nullptr, bool zero_in = false,
                                     bool need_norm = true)
 {
@@ -569,6 +584,9 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
                              rst ? coarse->f[MG3D_D] : nullptr, -1, -1, with_pro ? &pro->g : nullptr,
                              with_pro ? pro->f[MG3D_U] : nullptr);
             }
+            if (np < 0) /* nothing was launched: no buffer swap, no fold of partial sums that were never written */
+                return fail(MG3D_ERR_STATE, "fused sweep: no kernel for %d colour passes%s on level %d", S,
+                            res ? " + residual" : "", level);
             if (S > 0) {
                 double *t = l.f[MG3D_U];
                 l.f[MG3D_U] = l.alt;
@@ -581,7 +599,7 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
             }
             passes -= S;
         }
-        return;
+        return MG3D_OK;
     }
     const double hSq = l.h * l.h; /* mg_3d.h:644 */
     for (int it = 0; it < 2 * iters; it++) {
@@ -594,6 +612,7 @@ static void enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
         k_residual(l.g, l.f[MG3D_U], l.f[MG3D_D], invHsq, want_res == 2 ? l.f[MG3D_R] : nullptr, ctx->partials,
                    ctx->sumsq + slot, s);
     }
+    return MG3D_OK;
 }
 
 /* can the prolongation ride on the first smoothing launch?  (needs a smoothing-only first launch) */
@@ -614,14 +633,14 @@ static bool pro_fusable(const mg3d_ctx *ctx, int iters, int want_res)
     return !first_has_res;
 }
 
-static void enqueue_smooth(mg3d_ctx *ctx, int level, int post, int iters)
+static int enqueue_smooth(mg3d_ctx *ctx, int level, int post, int iters)
 {
-    enqueue_smooth_residual(ctx, level, post, iters, 0, 0);
+    return enqueue_smooth_residual(ctx, level, post, iters, 0, 0);
 }
 
-static void enqueue_residual(mg3d_ctx *ctx, int level, int store, int slot)
+static int enqueue_residual(mg3d_ctx *ctx, int level, int store, int slot)
 {
-    enqueue_smooth_residual(ctx, level, 0, 0, store ? 2 : 1, slot);
+    return enqueue_smooth_residual(ctx, level, 0, 0, store ? 2 : 1, slot);
 }
 
 extern "C" int mg3d_smooth(mg3d_ctx *ctx, int level, int post, int iters)
@@ -629,14 +648,14 @@ extern "C" int mg3d_smooth(mg3d_ctx *ctx, int level, int post, int iters)
     CHK(check_field_level(ctx, 0, level, "mg3d_smooth"));
     if (iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_smooth: negative iteration count");
-    enqueue_smooth(ctx, level, post, iters);
+    CHK(enqueue_smooth(ctx, level, post, iters));
     return launch_ok("mg3d_smooth");
 }
 
 extern "C" int mg3d_residual(mg3d_ctx *ctx, int level, int store, double *norm)
 {
     CHK(check_field_level(ctx, 0, level, "mg3d_residual"));
-    enqueue_residual(ctx, level, store, 0);
+    CHK(enqueue_residual(ctx, level, store, 0));
     CHK(launch_ok("mg3d_residual"));
     return read_norm(ctx, 0, norm);
 }
@@ -646,7 +665,7 @@ extern "C" int mg3d_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
     CHK(check_field_level(ctx, 0, level, "mg3d_smooth_residual"));
     if (iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_smooth_residual: negative iteration count");
-    enqueue_smooth_residual(ctx, level, post, iters, store ? 2 : 1, 0);
+    CHK(enqueue_smooth_residual(ctx, level, post, iters, store ? 2 : 1, 0));
     CHK(launch_ok("mg3d_smooth_residual"));
     return read_norm(ctx, 0, norm);
 }
@@ -657,7 +676,7 @@ extern "C" int mg3d_smooth_restrict(mg3d_ctx *ctx, int level, int iters)
     if (level < 1 || iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_smooth_restrict: bad level/iteration count");
     Level &lev = ctx->lv[level], &lc = ctx->lv[level - 1];
-    enqueue_smooth_residual(ctx, level, 0, iters, 2, ctx->sumsq_slots - 1, ctx->fused ? &lc : nullptr);
+    CHK(enqueue_smooth_residual(ctx, level, 0, iters, 2, ctx->sumsq_slots - 1, ctx->fused ? &lc : nullptr));
     k_restrict(lev.g, lev.f[MG3D_R], lc.g, lc.f[MG3D_D], ctx->stream, -1, -1, ctx->fused);
     return launch_ok("mg3d_smooth_restrict");
 }
@@ -719,24 +738,29 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
         if (ctx->fused) { /* pre-smoother and residual in one pass over the level (:1282 + :1294) */
             {
                 StageScope t(ctx, l, MG3D_ST_SMOOTH1);
-                enqueue_smooth_residual(ctx, l, 0, ctx->iters, 2, ctx->sumsq_slots - 1,
-                                        ctx->keep_r ? nullptr : &ctx->lv[l - 1], nullptr, zero_in, false);
+                CHK(enqueue_smooth_residual(ctx, l, 0, ctx->iters, 2, ctx->sumsq_slots - 1,
+                                            ctx->keep_r ? nullptr : &ctx->lv[l - 1], nullptr, zero_in, false));
             }
             StageScope t(ctx, l, MG3D_ST_RESIDUAL1); /* fused into the launch above: counted, ~0 s */
         } else {
             {
                 StageScope t(ctx, l, MG3D_ST_SMOOTH1);
-                enqueue_smooth(ctx, l, 0, ctx->iters); /* :1282 */
+                CHK(enqueue_smooth(ctx, l, 0, ctx->iters)); /* :1282 */
             }
             StageScope t(ctx, l, MG3D_ST_RESIDUAL1);
-            enqueue_residual(ctx, l, 1, ctx->sumsq_slots - 1); /* :1294 (norm discarded) */
+            CHK(enqueue_residual(ctx, l, 1, ctx->sumsq_slots - 1)); /* :1294 (norm discarded) */
         }
         {
             StageScope t(ctx, l, MG3D_ST_RESTRICT);
-            StageScope kt(ctx, l, MG3D_K_RESTRICT, true);
-            /* :1310; when the interior was restricted on the fly only the face injection (:879-958) is left */
-            k_restrict(lev.g, lev.f[MG3D_R], ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_D], s, -1, -1,
-                       ctx->fused && !ctx->keep_r);
+            /* :1310; when the interior was restricted on the fly only the face injection (:879-958) is left, and
+             * that only has something new to copy after r of this level or d of the coarser one was written from
+             * outside the cycle (faces_dirty) */
+            const bool faces_only = ctx->fused && !ctx->keep_r;
+            if (!faces_only || ctx->faces_dirty[l] || ctx->faces_always[l]) {
+                StageScope kt(ctx, l, MG3D_K_RESTRICT, true);
+                k_restrict(lev.g, lev.f[MG3D_R], ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_D], s, -1, -1, faces_only);
+                ctx->faces_dirty[l] = 0;
+            }
         }
     }
     {
@@ -763,18 +787,18 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
                 StageScope t(ctx, l, MG3D_ST_SMOOTH2);
                 /* the norm of a level below the top one is computed and dropped by the reference (:1320
                  * ignores the recursive call's value): skip it, nothing observable changes */
-                enqueue_smooth_residual(ctx, l, 1, ctx->iters, want_norm, slot, nullptr,
-                                        pro ? &ctx->lv[l - 1] : nullptr);
+                CHK(enqueue_smooth_residual(ctx, l, 1, ctx->iters, want_norm, slot, nullptr,
+                                            pro ? &ctx->lv[l - 1] : nullptr));
             }
             StageScope t(ctx, l, MG3D_ST_RESIDUAL2); /* fused into the launch above: counted, ~0 s */
         } else {
             {
                 StageScope t(ctx, l, MG3D_ST_SMOOTH2);
-                enqueue_smooth(ctx, l, 1, ctx->iters); /* :1341 */
+                CHK(enqueue_smooth(ctx, l, 1, ctx->iters)); /* :1341 */
             }
             StageScope t(ctx, l, MG3D_ST_RESIDUAL2);
             if (l == q)
-                enqueue_residual(ctx, l, 0, slot); /* :1354; below the top level the value is dropped (:1320) */
+                CHK(enqueue_residual(ctx, l, 0, slot)); /* :1354; below the top level the value is dropped (:1320) */
         }
     }
     return launch_ok("mg3d_vcycle");
@@ -827,6 +851,7 @@ extern "C" int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level)
 {
     CHK(check_field_level(ctx, field, level, "mg3d_fill_boundary"));
     k_fill_boundary(ctx->lv[level].g, ctx->lv[level].f[field], ctx->lv[level].h, ctx->stream);
+    mg3d_ctx_touched(ctx, field, level);
     return launch_ok("mg3d_fill_boundary");
 }
 

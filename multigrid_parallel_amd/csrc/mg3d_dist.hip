@@ -436,6 +436,8 @@ extern "C" int mg3d_dist_upload(mg3d_dist *D, int field, int level, const double
         const int N = g.N;
         HIPCHK(hipMemcpy2DAsync(p, g.pitch * sizeof(double), host + (size_t)g.ig0 * N * N, N * sizeof(double),
                                 N * sizeof(double), (size_t)g.ni * N, hipMemcpyHostToDevice, D->stream));
+        if (level < D->ld)
+            mg3d_ctx_touched(R.coarse, field, level);
     }
     HIPCHK(hipStreamSynchronize(D->stream));
     return MG3D_OK;
@@ -688,6 +690,9 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
                                    rst ? tgt[ri].gc : nullptr, rst ? tgt[ri].dc : nullptr, rst ? tgt[ri].lo : -1,
                                    rst ? tgt[ri].hi : -1, (pro && first) ? pro[ri].gc : nullptr,
                                    (pro && first) ? pro[ri].ec : nullptr, w_lo, w_hi);
+            if (np < 0) /* nothing was launched: no buffer swap, no fold */
+                return fail(MG3D_ERR_STATE, "slab sweep: no kernel for %d colour passes%s on level %d", S,
+                            res ? " + residual" : "", l);
             if (res && want_res == 1)
                 k_fold(cx->partials, np, cx->sumsq, s);
         }

@@ -29,8 +29,16 @@
  *
  * Geometry: a wave covers 64 k-pairs = 128 consecutive k; NW waves are stacked in j, each thread holding RJ
  * rows: tile = (NW*RJ) x 128 points including a halo of H = S (+1 with residual, +2 with restriction)
- * points on every side that is recomputed redundantly.  The i range is cut into chunks with H warm-up
- * planes each.  Output goes to a second array (the halo makes an in-place update racy between tiles).
+ * points on every side that is recomputed redundantly.  Output goes to a second array (the halo makes an
+ * in-place update racy between tiles).
+ *
+ * Work distribution: the launch is PERSISTENT -- one block per CU slot, and the (tile column, plane) space,
+ * linearised tile-major, is cut into gridDim.x equal shares.  A block marches through its share as one or two
+ * segments (the tail of one tile column, the head of the next), each with H warm-up planes: every CU gets the
+ * same number of steps, there is no partially filled last round of blocks, and a 513^3 level pays warm-up on
+ * ~1.4 segments of ~220 planes per block instead of one per 64..128-plane chunk.
+ * k-tiling: tiles start at multiples of 112 columns (128-byte aligned rows of 16 doubles) whenever that needs
+ * no more tiles than the tightest packing, so a tile row is exactly eight cache lines.
  */
 #include "mg3d_internal.h"
 
@@ -49,8 +57,11 @@ struct SweepArgs {
     double hSq, sixth, invHsq;
     int c1;         /* colour of the first pass: 1 red, 0 black */
     int ntj, ntk;   /* tiles in j, k */
-    int CI, nci;    /* planes per i-chunk, number of chunks */
-    int i_lo, i_hi;     /* local output planes this launch produces (chunks are cut from i_lo) */
+    int vk, hk;     /* k-tiling: tile tk covers columns [vk*tk, vk*tk + 128) and owns those at least hk from its
+                       edges (a tile edge on the global boundary needs no halo); vk = 128 - 2*hk */
+    int snap;       /* segment cuts closer than this to a tile column's end move onto it */
+    int CI;         /* > 0: lock-step mode, planes per i-chunk; 0: equal shares of the linearised work */
+    int i_lo, i_hi;     /* local output planes this launch produces */
     int acc_lo, acc_hi; /* local planes whose diff^2 enter the norm (owned planes of a slab) */
     /* fused prolongation (PRO): the level's input is vin + P(ec) (mg_3d.h:1000-1145); gce = geometry of ec */
     const double *ec;
@@ -59,7 +70,7 @@ struct SweepArgs {
     Geom gc;
     double *dc;
     int ic_lo, ic_hi;
-    int xcd_remap;  /* 1: renumber blocks so that consecutive tiles share an XCD (and its L2) */
+    int xcd_remap;  /* 1: blocks of one XCD group (blockIdx % 8) take consecutive shares of the work */
 };
 
 /* RES: 0 = smoothing only, 1 = + residual (r store and/or norm), 2 = + residual AND full-weighting
@@ -107,8 +118,8 @@ template <int S, int RES, int RJ, int NW, int PF, bool PRO>
 __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 {
     using Sh = SweepShape<S, RES>;
-    constexpr int ST = Sh::ST, HJ = Sh::HJ, HK = Sh::HK, HI = Sh::HI;
-    constexpr int TJ = NW * RJ, VJ = TJ - 2 * HJ, VK = 2 * WAVE - 2 * HK;
+    constexpr int ST = Sh::ST, HJ = Sh::HJ, HI = Sh::HI;
+    constexpr int TJ = NW * RJ, VJ = TJ - 2 * HJ;
     static_assert(RJ % 2 == 0, "RJ must be even (row parity of a wave's first row)");
     static_assert(VJ > 0 && ST >= 1, "tile too small");
     constexpr int STX = ST > 0 ? ST : 1;
@@ -122,32 +133,54 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     __shared__ double cpl[PRO ? 3 : 1][CRW][CCW];
 
     const Geom &g = a.g;
+    /* the wave index through readfirstlane: the compiler then knows that everything derived from it (the row
+     * flags below) is wave-uniform and keeps it in scalar registers and scalar branches instead of 64-bit lane
+     * masks -- the residual variants of this kernel were bound by the CU's one scalar ALU, not by memory */
+#ifdef MG3D_NO_UNIFORM_W
     const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-    int b = blockIdx.x;
-    if (a.xcd_remap == 2) {
-        /* banded: every chunk's tiles are dealt in 8 contiguous bands, band x to the blocks with b % 8 == x,
-         * so all XCDs sweep the same chunk at the same time and the j-halos of a band stay in one L2.
-         * The grid is padded to a multiple of 8 tiles per chunk; surplus blocks exit. */
-        const int per = (a.ntj * a.ntk + 7) >> 3, x = b & 7, idx = b >> 3;
-        const int cch = idx / per, t = x * per + idx % per;
-        if (t >= a.ntj * a.ntk)
-            return;
-        b = cch * a.ntj * a.ntk + t;
-    } else if (a.xcd_remap) {
-        /* hardware deals blocks round-robin over the 8 XCDs (b % 8 names the XCD group, never which XCD);
-         * give each group a contiguous run of tiles so halo re-reads hit that XCD's L2.  Speed only. */
-        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = b & 7, idx = b >> 3;
-        b = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+#else
+    const int lane = threadIdx.x & (WAVE - 1), w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+#endif
+    /* this block's share [w0, w1) of the linearised (tile column, output plane) space */
+    const int nout = a.i_hi - a.i_lo;
+    const long long W = (long long)a.ntj * a.ntk * nout;
+    int vb = blockIdx.x;
+    if (a.xcd_remap) {
+        /* hardware deals blocks round-robin over the 8 XCDs (b % 8 names the XCD group, never which XCD); give
+         * each group a contiguous run of shares.  Speed only. */
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = vb & 7, idx = vb >> 3;
+        vb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
     }
-    const int tk = b % a.ntk;
-    b /= a.ntk;
-    const int tj = b % a.ntj;
-    const int ci = b / a.ntj;
+    auto cut = [&](int k) -> long long {
+        long long x = W * k / gridDim.x;
+        const int r = (int)(x % nout);
+        if (r < a.snap)
+            x -= r;
+        else if (nout - r < a.snap)
+            x += nout - r;
+        return x;
+    };
+    long long w0 = cut(vb), w1 = cut(vb + 1);
+    if (a.CI > 0) {
+        /* lock-step mode: block -> (tile column, i-chunk), tile fastest: all tile columns of a chunk march through
+         * the same planes at the same time, so a neighbour's halo rows are still in the Infinity Cache / L2 */
+        const int T = a.ntj * a.ntk, tl = vb % T, ch = vb / T;
+        w0 = (long long)tl * nout + (long long)ch * a.CI;
+        w1 = min(w0 + a.CI, (long long)(tl + 1) * nout);
+    }
+    double acc = 0.;
 
-    const int jt0 = tj * VJ - HJ, kt0 = tk * VK - HK;
+    for (; w0 < w1;) {
+    const int t_lin = (int)(w0 / nout), off = (int)(w0 - (long long)t_lin * nout);
+    const int len = (int)min((long long)(nout - off), w1 - w0);
+    w0 += len;
+    const int tk = t_lin % a.ntk, tj = t_lin / a.ntk;
+
+    const int jt0 = tj * VJ - HJ, kt0 = tk * a.vk;
+    const int own_klo = tk == 0 ? 0 : kt0 + a.hk, own_khi = tk == a.ntk - 1 ? g.nk : kt0 + 2 * WAVE - a.hk;
     const int jrow0 = jt0 + w * RJ;
     const int kA = kt0 + 2 * lane; /* column 0 of the pair; column 1 = kA + 1 */
-    const int i_out0 = a.i_lo + ci * a.CI, i_out1 = min(i_out0 + a.CI, a.i_hi);
+    const int i_out0 = a.i_lo + off, i_out1 = i_out0 + len;
     /* start plane: HI warm-up planes, one more if needed so that the column active at
      * local step p in row rr is (p + rr) & 1 */
     int i_s = i_out0 - HI;
@@ -168,8 +201,13 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     }
     const bool col_in[2] = {kA >= 0 && kA < g.nk, kA + 1 >= 0 && kA + 1 < g.nk};
     const bool col_upd[2] = {kA >= 1 && kA <= g.nk - 2, kA + 1 >= 1 && kA + 1 <= g.nk - 2};
-    const bool pair_own = kA >= tk * VK && kA < (tk + 1) * VK && col_in[0];
+    const bool pair_own = kA >= own_klo && kA < own_khi && col_in[0];
     const bool pair_load = col_in[0]; /* kA even and pitch even: the 16-byte load stays inside the row */
+    /* lane masks used inside the plane loop (the row flags are wave-uniform scalars) */
+    const bool own_upd[2] = {pair_own && col_upd[0], pair_own && col_upd[1]};
+    const bool own_both = own_upd[0] && own_upd[1], own_only0 = own_upd[0] && !col_upd[1],
+               own_only1 = own_upd[1] && !col_upd[0];
+    const bool k_edge_tile = tk == 0 || tk == a.ntk - 1; /* only there a pair can have one updatable column */
 
     /* pipeline state (see header).  last[rr][s][c]: newest stage-s output of column c */
     double last[RJ][STX][2], in_prev[RJ][2], dring[RJ][ST + 1][2], rkeep[RJ];
@@ -186,7 +224,6 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         rkeep[rr] = 0.;
         cur_v[rr] = make_double2(0., 0.);
     }
-    double acc = 0.;
     double2 rcur[RJ], rlag[RJ]; /* RES == 2: r pairs of the plane finished this step / the step before */
     double racc[RJ / 2];        /* running 27-point sums, one per coarse row centred in this thread's rows */
 #pragma unroll
@@ -330,11 +367,12 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
             e_bot[s] = (w < NW - 1) ? ex[par ^ 1][w + 1][0][s][lane] : 0.;
         }
         /* which planes may be updated (global boundary planes / slab halos are not) */
-        bool pl_upd[STX + 1];
+        bool pl_upd[STX + 1], acc_ok[STX + 1];
 #pragma unroll
         for (int s = 1; s <= ST; s++) {
             const int q = i - s;
             pl_upd[s] = q >= 1 && q <= g.ni - 2 && (g.ig0 + q) >= 1 && (g.ig0 + q) <= g.N - 2;
+            acc_ok[s] = q >= i_out0 && q < i_out1 && q >= a.acc_lo && q < a.acc_hi; /* planes that enter the norm */
         }
 
 #pragma unroll
@@ -364,35 +402,35 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                 sum = sum + jp;
                 sum = sum + km;
                 sum = sum + kp;
-                const bool upd = row_upd[rr] && col_upd[X] && pl_upd[s];
+                const bool updu = row_upd[rr] && pl_upd[s]; /* wave-uniform part of "this point is updated" */
                 if (s <= S) {
                     const double val = a.sixth * (sum - a.hSq * dd); /* mg_3d.h:438-443 */
-                    nw[s] = upd ? val : center;
+                    nw[s] = (updu && col_upd[X]) ? val : center;
                     if (RES && s == S) { /* residual of the point just updated: same six neighbours */
                         const double diff = dd - a.invHsq * (sum - 6 * nw[s]); /* mg_3d.h:819-821 */
                         diffs[0] = diff;
-                        const int q = i - s;
-                        if (upd && row_own[rr] && pair_own && q >= i_out0 && q < i_out1 && q >= a.acc_lo && q < a.acc_hi)
-                            acc += diff * diff;
+                        /* adding +0 leaves a sum of squares unchanged: a select, not a branch */
+                        if (a.partials && updu && row_own[rr] && acc_ok[s])
+                            acc += own_upd[X] ? diff * diff : 0.;
                     }
                 } else {
                     const double diff = dd - a.invHsq * (sum - 6 * center); /* mg_3d.h:819-821 */
                     nw[s] = center;
                     diffs[S > 0 ? 1 : s - 1] = diff;
-                    const int q = i - s;
-                    if (upd && row_own[rr] && pair_own && q >= i_out0 && q < i_out1 && q >= a.acc_lo && q < a.acc_hi)
-                        acc += diff * diff;
+                    if (a.partials && updu && row_own[rr] && acc_ok[s])
+                        acc += own_upd[X] ? diff * diff : 0.;
                 }
             }
             /* ---- stores: v' of plane i-S, r of plane i-S-2 (pairs complete at this step) */
             if constexpr (S > 0) {
                 const int q = i - S;
-                if (q >= i_out0 && q < i_out1 && row_own[rr] && pair_own) {
+                if (q >= i_out0 && q < i_out1 && row_own[rr]) { /* wave-uniform */
                     const double other = last[rr][S - 1][X ^ 1]; /* finished one step ago */
                     double2 o;
                     o.x = X ? other : nw[S];
                     o.y = X ? nw[S] : other;
-                    *reinterpret_cast<double2 *>(a.vout + g.plane * q + row_off[rr]) = o;
+                    if (pair_own)
+                        *reinterpret_cast<double2 *>(a.vout + g.plane * q + row_off[rr]) = o;
                 }
             }
             if constexpr (RES != 0) {
@@ -402,14 +440,16 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                 o.x = X ? rkeep[rr] : diffs[1];
                 o.y = X ? diffs[1] : rkeep[rr];
                 rcur[rr] = o;
-                if (a.r && q >= i_out0 && q < i_out1 && row_own[rr] && pair_own && row_upd[rr] && pl_upd[ST]) {
+                if (a.r && q >= i_out0 && q < i_out1 && row_own[rr] && row_upd[rr] && pl_upd[ST]) { /* wave-uniform */
                     double *dst = a.r + g.plane * q + row_off[rr];
-                    if (col_upd[0] && col_upd[1])
+                    if (own_both)
                         *reinterpret_cast<double2 *>(dst) = o;
-                    else if (col_upd[0])
-                        dst[0] = o.x;
-                    else if (col_upd[1])
-                        dst[1] = o.y; /* boundary entries of r are never written (mg_3d.h:824-825) */
+                    if (k_edge_tile) { /* boundary entries of r are never written (mg_3d.h:824-825) */
+                        if (own_only0)
+                            dst[0] = o.x;
+                        if (own_only1)
+                            dst[1] = o.y;
+                    }
                 }
                 rkeep[rr] = diffs[0];
             }
@@ -446,8 +486,10 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                     const int icg = (qg - 1) >> 1, icl = icg - a.gc.ig0, cen = qq - 1;
                     const int jc = (jrow0 + 2 * c) >> 1, kc = kA >> 1;
                     if (cen >= i_out0 && cen < i_out1 && icg >= 1 && icg <= a.gc.N - 2 && icl >= a.ic_lo && icl < a.ic_hi &&
-                        row_own[2 * c] && jc >= 1 && jc <= a.gc.nj - 2 && pair_own && kc >= 1 && kc <= a.gc.nk - 2)
-                        a.dc[a.gc.plane * icl + (long long)a.gc.pitch * jc + kc] = run;
+                        row_own[2 * c] && jc >= 1 && jc <= a.gc.nj - 2) { /* wave-uniform */
+                        if (pair_own && kc >= 1 && kc <= a.gc.nk - 2)
+                            a.dc[a.gc.plane * icl + (long long)a.gc.pitch * jc + kc] = run;
+                    }
                     double fresh = 0.;
 #pragma unroll
                     for (int t = 0; t < 9; t++)
@@ -492,6 +534,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     }
     if (pl < nsteps)
         step(pl, std::integral_constant<int, 0>{});
+    } /* segments */
 
     if (RES && a.partials) {
 #pragma unroll
@@ -510,66 +553,92 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 }
 
 /* -------------------------------------------------------------------- launch */
+static int device_cus()
+{
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            n = p.multiProcessorCount;
+        if (n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
 template <int S, int RES, int RJ, int NW, int PF, bool PRO = false>
 static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
 {
     using Sh = SweepShape<S, RES>;
-    constexpr int VJ = NW * RJ - 2 * Sh::HJ, VK = 2 * WAVE - 2 * Sh::HK;
+    constexpr int VJ = NW * RJ - 2 * Sh::HJ;
     const Geom &g = a.g;
     a.ntj = (g.nj + VJ - 1) / VJ;
-    a.ntk = (g.nk + VK - 1) / VK;
-    /* i-chunk length: every chunk pays `ovh` extra steps (warm-up planes, pipeline drain), but a level needs
-     * a few hundred blocks to keep 256 CUs busy (one 512-thread block per CU) and short chunks mean fewer
-     * dependent steps.  Measured optimum on MI355X: about 500-1000 blocks for a full level (513^3: CI 64-128,
-     * 257^3: 16, 129^3: 8, <= 65^3: 2-4; pure residual launches tolerate shorter chunks). */
+    /* k-tiling: tiles of 128 columns starting at multiples of vk = 128 - 2*hk, hk >= HK.  The first and the last
+     * tile own their columns up to the global boundary (no halo needed there), so T tiles cover vk*(T-1) + 128
+     * columns.  hk = 8 puts every tile on cache-line boundaries; it is taken whenever it costs no extra tile. */
+    auto tiles_for = [&](int vk) { return g.nk <= 2 * WAVE ? 1 : (g.nk - 2 * WAVE + vk - 1) / vk + 1; };
+    const int vk_tight = 2 * WAVE - 2 * Sh::HK, vk_line = 2 * WAVE - 16;
+    a.vk = (Sh::HK <= 8 && tiles_for(vk_line) <= tiles_for(vk_tight)) ? vk_line : vk_tight;
+    if (const char *e = getenv("MG3D_SWEEP_VK"))
+        if (atoi(e) == 1)
+            a.vk = vk_tight;
+    a.hk = (2 * WAVE - a.vk) / 2;
+    a.ntk = tiles_for(a.vk);
+    /* i-chunks, lock-step: block -> (tile column, chunk), tile fastest, so that all tile columns of a chunk march
+     * through the same planes at the same time (a neighbour's halo rows are then still in the Infinity Cache / L2:
+     * measured 1.3-1.5x faster than handing every CU an equal share of unsynchronised work).  Every shape needs > 128
+     * VGPRs at 512 threads (one block per CU), so a launch runs in rounds of `ncu` blocks and costs about
+     *      max( rounds * (CI + ovh),  blocks * (CI + ovh) / (sat * ncu) )   steps
+     * -- the critical path of a CU, or, once about 80 % of the CUs stream, the memory system (513^3, four passes:
+     * 2 chunks = 220 blocks, one round: 0.71 ms; 3 chunks = 330 blocks, two rounds: 0.95 ms; 4 chunks: 0.77 ms).
+     * ovh = warm-up planes + pipeline drain per chunk.  Ties go to fewer chunks (fewer warm-up planes to read). */
     const int nout = a.i_hi - a.i_lo;
-    auto blocks = [&](int ci) { return (long long)a.ntj * a.ntk * ((nout + ci - 1) / ci); };
+    const int ncu = device_cus();
+    const long long T = (long long)a.ntj * a.ntk;
     const int ovh = Sh::HI + Sh::ST + (RES == 2 ? 2 : 0) + 1;
-    int CI = RES == 2 ? 16 : 8; /* the fused restriction pays two more warm-up planes and two drain steps */
-    const long long most = RES == 2 ? 1000 : Sh::ST <= 2 ? 1600 : 800;
-    while (CI < 128 && blocks(CI) > most)
-        CI *= 2;
-    while (CI > 2 && blocks(CI) < 100)
-        CI /= 2;
-    /* a thin plane range (an i-slab of a multi-GPU run): if some exact division fits in ONE round of blocks
-     * and clearly beats the multi-round choice above, take it (68 planes of 513^2: 2 chunks of 34) */
-    if (blocks(CI) > 256) {
-        /* one 512-thread block per CU (every shape needs > 128 VGPRs): up to two rounds are counted whole (380
-         * blocks take as long as 512), beyond that the tail overlaps well enough for the fractional figure */
-        static const int whole = getenv("MG3D_SLAB_ROUNDS") ? atoi(getenv("MG3D_SLAB_ROUNDS")) : 1;
-        const double cur = ((whole == 2 || (whole == 1 && blocks(CI) <= 512)) ? (double)((blocks(CI) + 255) / 256)
-                                                                             : (double)blocks(CI) / 256.0) * (CI + ovh);
-        for (int k = 1; k <= 8; k++) {
-            const int ci = (nout + k - 1) / k;
-            if (ci >= 2 && blocks(ci) <= 256 && (double)(ci + ovh) < 0.9 * cur) {
-                CI = ci;
-                break; /* smallest k = fewest, longest chunks that already fit... keep the first that fits */
-            }
+    int best_nci = 1;
+    double best_cost = 1e30;
+    for (int nci = 1; nci <= 64 && nci <= nout; nci++) {
+        const int ci = (nout + nci - 1) / nci;
+        if (nci > 1 && ci < 2)
+            break;
+        const long long blocks = T * ((nout + ci - 1) / ci);
+        if (a.partials && blocks > max_partials)
+            break;
+        const double steps = (double)(ci + ovh);
+        /* the four-pass launch saturates the memory system with ~80 % of the CUs streaming; the shorter pipelines
+         * (two passes + residual, residual + restriction, prolongation + two passes) spend more of a step computing
+         * and keep scaling to all of them */
+        const double sat = S >= 4 && RES == 0 ? 0.8 : 1.0;
+        const double crit = (double)((blocks + ncu - 1) / ncu) * steps, bw = (double)blocks * steps / (sat * ncu);
+        const double cost = crit > bw ? crit : bw;
+        if (cost < best_cost * 0.97) {
+            best_cost = cost;
+            best_nci = nci;
         }
     }
+    a.CI = (nout + best_nci - 1) / best_nci;
     if (const char *e = getenv("MG3D_SWEEP_CI"))
-        CI = atoi(e) > 0 ? atoi(e) : CI;
-    while (a.partials && blocks(CI) + 8 > max_partials && CI < nout)
-        CI *= 2; /* one partial sum per block must fit the caller's buffer */
-    if (CI > nout)
-        CI = nout;
-    if (CI < 1)
-        CI = 1;
-    a.CI = CI;
-    a.nci = (nout + CI - 1) / CI;
-    /* measured on MI355X (513^3, S=4): the remap cuts L2 misses by 20 % but runs 5-10 % slower; off by default */
-    a.xcd_remap = 0;
+        if (atoi(e) > 0)
+            a.CI = atoi(e) < nout ? atoi(e) : nout;
+    long long nb = T * ((nout + a.CI - 1) / a.CI);
+    a.snap = 0;
+    /* one round: give each XCD group (blockIdx % 8) a contiguous run of tile columns -- neighbours then share an L2
+     * (2 % at 513^3).  With several rounds the renumbering would scatter the first round over all chunks. */
+    a.xcd_remap = nb <= ncu && nb >= 64;
     if (const char *e = getenv("MG3D_XCD"))
-        a.xcd_remap = atoi(e);
-    if (a.xcd_remap == 2 && (long long)a.ntj * a.ntk < 16)
-        a.xcd_remap = 0;
-    long long nb = (long long)a.ntj * a.ntk * a.nci;
-    if (a.xcd_remap == 2)
-        nb = (long long)(((a.ntj * a.ntk + 7) >> 3) << 3) * a.nci;
+        a.xcd_remap = atoi(e) == 1;
+    if (getenv("MG3D_SWEEP_BALANCED") && getenv("MG3D_SWEEP_BALANCED")[0] == '1') {
+        /* experiment: equal shares of the linearised (tile column, plane) space, one block per CU, no lock-step */
+        a.CI = 0;
+        nb = ncu;
+        if ((long long)T * nout / nb < 4)
+            nb = (long long)T * nout / 4 > 0 ? (long long)T * nout / 4 : 1;
+        a.snap = ((long long)T * nout / nb >= 4 * ovh) ? ovh : 0;
+    }
     if (a.partials && nb > max_partials)
         return -1;
-    if (a.partials && a.xcd_remap == 2)
-        (void)hipMemsetAsync(a.partials, 0, sizeof(double) * nb, s); /* surplus blocks write nothing */
     hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
     return (int)nb;
 }
@@ -590,36 +659,38 @@ static SweepCfg env_cfg(SweepCfg dflt)
     return dflt;
 }
 
+/* the first shape listed is the default; an MG3D_SWEEP_CFG that names no compiled shape falls back to it */
 #define TRY(S_, RES_, RJ_, NW_, PF_)                                              \
     if (c.rj == RJ_ && c.nw == NW_ && c.pf == PF_)                                \
         return launch_sweep<S_, RES_, RJ_, NW_, PF_>(a, max_partials, s);
+#define DFLT(S_, RES_, RJ_, NW_, PF_) return launch_sweep<S_, RES_, RJ_, NW_, PF_>(a, max_partials, s);
 
 template <int S, int RES> static int dispatch(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s);
 
 template <> int dispatch<4, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(4, 1, 6, 4, 1) TRY(4, 1, 6, 4, 2) TRY(4, 1, 4, 4, 2) TRY(4, 1, 4, 8, 1) TRY(4, 1, 2, 8, 2)
-    return -1;
+    DFLT(4, 1, 6, 4, 2)
 }
 template <> int dispatch<4, 0>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(4, 0, 8, 4, 1) TRY(4, 0, 6, 4, 2) TRY(4, 0, 6, 4, 3) TRY(4, 0, 4, 8, 1) TRY(4, 0, 4, 8, 2)
-    return -1;
+    DFLT(4, 0, 4, 8, 1)
 }
 template <> int dispatch<2, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(2, 1, 4, 8, 1) TRY(2, 1, 8, 4, 2) TRY(2, 1, 6, 4, 2)
-    return -1;
+    DFLT(2, 1, 4, 8, 1)
 }
 template <> int dispatch<2, 0>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(2, 0, 6, 8, 1) TRY(2, 0, 8, 4, 2) TRY(2, 0, 4, 8, 1) TRY(2, 0, 4, 8, 2) TRY(2, 0, 4, 8, 3)
-    return -1;
+    DFLT(2, 0, 4, 8, 1)
 }
 template <> int dispatch<0, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(0, 1, 4, 8, 1) TRY(0, 1, 8, 4, 2) TRY(0, 1, 4, 8, 2) TRY(0, 1, 4, 8, 3) TRY(0, 1, 2, 8, 4)
-    return -1;
+    DFLT(0, 1, 4, 8, 1)
 }
 
 /* S colour passes starting with colour c1, optional residual.  Returns the number of
@@ -627,12 +698,12 @@ template <> int dispatch<0, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
 template <> int dispatch<0, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(0, 2, 4, 8, 1) TRY(0, 2, 4, 8, 2)
-    return -1;
+    DFLT(0, 2, 4, 8, 2)
 }
 template <> int dispatch<2, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(2, 2, 4, 8, 1)
-    return -1;
+    DFLT(2, 2, 4, 8, 1)
 }
 
 int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
@@ -668,12 +739,11 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
     a.invHsq = 1. / (h * h); /* mg_3d.h:797 */
     a.c1 = c1;
     if (ec) { /* prolongation fused into the input: 4- and 2-pass smoothing launches */
-        SweepCfg c = env_cfg({4, 8, 1});
         if (dc || residual || (g.nj & 1) == 0)
             return -1;
-        if (S == 4 && c.rj == 4 && c.nw == 8 && c.pf == 1)
+        if (S == 4)
             return launch_sweep<4, 0, 4, 8, 1, true>(a, max_partials, s);
-        if (S == 2 && c.rj == 4 && c.nw == 8 && c.pf == 1)
+        if (S == 2)
             return launch_sweep<2, 0, 4, 8, 1, true>(a, max_partials, s);
         return -1;
     }

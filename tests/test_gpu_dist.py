@@ -85,6 +85,7 @@ def test_single_rank_builds_real_communicators(monkeypatch):
         assert np.array_equal(d.download(MG3D_U, 3), want_u)
     np.testing.assert_allclose(norms, want_norms, rtol=1e-11)
     monkeypatch.delenv("MG3D_OVERLAP")
+    uid = M.DistSolver.unique_id()  # a unique id serves one communicator
     with M.DistSolver(5, 4, 2, rank=0, nranks=1, unique_id=uid) as d:  # the RCCL default: one communicator, no overlap
         assert d.comm_info()[:2] == (1, False)
         d.setup_test_problem()

@@ -44,6 +44,7 @@ cases = {
     "S0RST": (lambda: s.smooth_restrict(lev, 0), 4.125 * n * 8, ["4,8,1", "4,8,2"]),
     "S2RST": (lambda: s.smooth_restrict(lev, 1), 7.125 * n * 8, ["4,8,1"]),
     "S0NORM": (lambda: s.residual(lev, False, False), 2 * n * 8, ["4,8,1", "8,4,2", "4,8,2", "4,8,3", "2,8,4"]),
+    "S2NORM": (lambda: s.smooth_residual(lev, 1, 1, False, False), 5 * n * 8, ["4,8,1"]),
 }
 only = os.environ.get("ONLY")
 cfg_override = os.environ.get("CFGS")
@@ -56,8 +57,10 @@ for name, (fn, alg, cfgs) in cases.items():
             os.environ["MG3D_SWEEP_CI"] = ci
             for xcd in os.environ.get("XCDS", "0").split(","):
                 os.environ["MG3D_XCD"] = xcd
-                t = timeit(fn)
-                print(f"{name:6s} cfg {cfg:6s} CI {ci:>3s} xcd {xcd}: {t * 1e3:8.3f} ms   algorithmic {alg / t / 1e9:8.1f} GB/s", flush=True)
+                for vk in os.environ.get("VKS", "0").split(","):  # 0: line-aligned k-tiles when free, 1: tightest packing
+                    os.environ["MG3D_SWEEP_VK"] = vk
+                    t = timeit(fn)
+                    print(f"{name:6s} cfg {cfg:6s} CI {ci:>3s} xcd {xcd} vk {vk}: {t * 1e3:8.3f} ms   algorithmic {alg / t / 1e9:8.1f} GB/s", flush=True)
 if os.environ.get("NO_UNFUSED"):
     sys.exit(0)
 os.environ["MG3D_NO_FUSE"] = "1"
