@@ -170,44 +170,78 @@ def self_launch(args):
 
 
 def f32_line(args):
-    """One JSON line for the fp32 / damped-Jacobi / F-cycle variant (1 GPU).  Not the headline metric."""
+    """One JSON line for the fp32 / damped-Jacobi / F-cycle variant (BASELINE configs[4]; parity unpinned).  Not the
+    headline metric.  --gpus N > 1 (under torch.distributed.run, or self-launched): the same problem on N i-slabs."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    force_dist = os.environ.get("MG3D_BENCH_FORCE_DIST") == "1"
+    if world > 1 or (force_dist and "RANK" in os.environ):
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import multigrid_parallel_amd as M
     c, nu = args.coarse, args.nu
     L = args.levels if args.levels != 7 else 8
     N = (c - 1) * (1 << (L - 1)) + 1
     alg = sum((3 * 2 * nu + 8) * ((c - 1) * (1 << l) + 1) ** 3 * 4 + 3 * ((c - 1) * (1 << (l - 1)) + 1) ** 3 * 4
               for l in range(1, L)) + (c ** 6 + 2 * c ** 3) * 8
-    with M.Solver32(c, L, nu) as s:
-        s.setup_test_problem(fmg=False)
-        s.vcycles(args.warmup)
+    comp = compulsory_bytes_per_cycle(c, L, w=4) - (c ** 6 + 2 * c ** 3) * 4 + (c ** 6 + 2 * c ** 3) * 8  # LU in double
+    if world > 1 or force_dist:
+        uid = [M.DistSolver.unique_id() if rank == 0 else None]
+        if dist.is_initialized():
+            dist.broadcast_object_list(uid, src=0)
+        s = M.DistSolver32(c, L, nu, rank=rank, nranks=world, unique_id=uid[0], device=local_rank)
+        par = f"{world} GPUs, i-slabs, halo {s.halo} planes, levels >= {s.first_level} distributed, RCCL send/recv"
+    else:
+        s = M.Solver32(c, L, nu)
+        par = "1 GPU"
+
+    def barrier():
+        if dist.is_initialized():
+            dist.barrier()
         s.sync()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        norms = s.vcycles(args.steps)
-        s.sync()
-        torch.cuda.synchronize()
-        per = (time.perf_counter() - t0) / args.steps
-        t0 = time.perf_counter()
-        s.setup_test_problem(fmg=True)
-        s.sync()
-        t_fmg = time.perf_counter() - t0
-        after = s.vcycles(1)
-    print(json.dumps({
-        "metric": f"V-cycles/sec, {N}^3 Poisson, fp32, damped-Jacobi V({nu},{nu}) after an F-cycle start (parity unpinned)",
-        "value": 1.0 / per, "unit": "V-cycles/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": per * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": f"{N}^3 Poisson (args {c} {L} {nu}), Dirichlet x^2-2y^2+z^2, omega 6/7, device-resident",
-                   "coarse_pts": c, "levels": L, "smooth_iters": nu, "parallelism": "1 GPU"},
-        "fcycle_start_ms": t_fmg * 1e3, "first_norm": float(norms[0]), "last_norm": float(norms[-1]),
-        "norm_after_fcycle_start": float(after[0]),
-        "roofline": {"bound": "hbm", "kernel": "whole V-cycle (algorithmic bytes of SURVEY 8(d), w = 4)",
-                     "achieved": alg / per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg / per / 1e9 / HBM_PEAK_GBS, "traffic": None},
-        "cpu_baseline": None}))
+
+    s.setup_test_problem(fmg=False)
+    s.vcycles(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    norms = s.vcycles(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist.is_initialized():
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    per = elapsed / args.steps
+    barrier()
+    t0 = time.perf_counter()
+    s.setup_test_problem(fmg=True)
+    barrier()
+    t_fmg = time.perf_counter() - t0
+    after = s.vcycles(1)
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"V-cycles/sec, {N}^3 Poisson, fp32, damped-Jacobi V({nu},{nu}) after an F-cycle start (parity unpinned)",
+            "value": 1.0 / per, "unit": "V-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": per * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{N}^3 Poisson (args {c} {L} {nu}), Dirichlet x^2-2y^2+z^2, omega 6/7, device-resident",
+                       "coarse_pts": c, "levels": L, "smooth_iters": nu, "parallelism": par},
+            "fcycle_start_ms": t_fmg * 1e3, "first_norm": float(norms[0]), "last_norm": float(norms[-1]),
+            "norm_after_fcycle_start": float(after[0]),
+            "roofline": {"bound": "hbm", "kernel": "whole V-cycle (compulsory bytes: every leg streams its fields once, w = 4)",
+                         "achieved": comp / per / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                         "frac": comp / per / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                         "frac_survey_credit": alg / per / 1e9 / (HBM_PEAK_GBS * world)},
+            "cpu_baseline": None}))
+    s.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def main():
@@ -229,11 +263,11 @@ def main():
     args = ap.parse_args()
     if args.cpu_child:
         return cpu_child(args)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)  # plain `python bench.py --gpus N`: become the launcher, one child rank per GPU
     if args.f32:
         return f32_line(args)
 
-    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
-        return self_launch(args)  # plain `python bench.py --gpus N`: become the launcher, one child rank per GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -222,6 +222,26 @@ int mg3d32_coarse_solve(mg3d32_ctx *ctx);                          /* gauss_elim
 int mg3d32_vcycles(mg3d32_ctx *ctx, int count, double *norms);     /* mg_3d.h:1242-1362 with the Jacobi smoother */
 int mg3d32_fmg_initialize(mg3d32_ctx *ctx);                        /* F-cycle start, mg_dirichlet_analytic.c:771-806 */
 
+/* The same variant on i-slabs of several GPUs (csrc/mg3d_f32_dist.hip; BASELINE configs[4]: 1025^3 on 8 GPUs): the
+ * partition and schedule of mg3d_dist_* with H = smooth_iters + 2 halo planes (a Jacobi sweep uses up one plane per
+ * sweep).  unique_id as for mg3d_dist_create; NULL = loopback (all ranks virtual in this process).  upload/download
+ * take the FULL N^3 float array. */
+typedef struct mg3d32_dist mg3d32_dist;
+int mg3d32_slab_halo(int smooth_iters);
+int mg3d32_dist_create(int coarse_pts, int num_levels, int smooth_iters, double omega, double grid_length, int rank,
+                       int nranks, const void *unique_id, int device, mg3d32_dist **out);
+int mg3d32_dist_destroy(mg3d32_dist *d);
+int mg3d32_dist_first_level(const mg3d32_dist *d);
+int mg3d32_dist_halo(const mg3d32_dist *d);
+int mg3d32_dist_comm_info(const mg3d32_dist *d, int *rccl_ranks, int *device);
+int mg3d32_dist_upload(mg3d32_dist *d, int field, int level, const float *host_full);
+int mg3d32_dist_download(mg3d32_dist *d, int field, int level, float *host_full);
+int mg3d32_dist_zero(mg3d32_dist *d, int field, int level);
+int mg3d32_dist_fill_boundary(mg3d32_dist *d, int field, int level);
+int mg3d32_dist_vcycles(mg3d32_dist *d, int count, double *norms);
+int mg3d32_dist_fmg_initialize(mg3d32_dist *d); /* needs d of every level (boundary values), u zero */
+int mg3d32_dist_sync(mg3d32_dist *d);
+
 #ifdef __cplusplus
 }
 #endif

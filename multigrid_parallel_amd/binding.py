@@ -114,6 +114,20 @@ SIGNATURES = {
     "mg3d32_coarse_solve": (C.c_int, [C.c_void_p]),
     "mg3d32_vcycles": (C.c_int, [C.c_void_p, C.c_int, dp]),
     "mg3d32_fmg_initialize": (C.c_int, [C.c_void_p]),
+    "mg3d32_slab_halo": (C.c_int, [C.c_int]),
+    "mg3d32_dist_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_int, C.POINTER(C.c_void_p)]),
+    "mg3d32_dist_destroy": (C.c_int, [C.c_void_p]),
+    "mg3d32_dist_first_level": (C.c_int, [C.c_void_p]),
+    "mg3d32_dist_halo": (C.c_int, [C.c_void_p]),
+    "mg3d32_dist_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mg3d32_dist_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, fp]),
+    "mg3d32_dist_download": (C.c_int, [C.c_void_p, C.c_int, C.c_int, fp]),
+    "mg3d32_dist_zero": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mg3d32_dist_fill_boundary": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mg3d32_dist_vcycles": (C.c_int, [C.c_void_p, C.c_int, dp]),
+    "mg3d32_dist_fmg_initialize": (C.c_int, [C.c_void_p]),
+    "mg3d32_dist_sync": (C.c_int, [C.c_void_p]),
 }
 
 
@@ -496,3 +510,83 @@ class Solver32:
         norms = np.zeros(count)
         check(self.L.mg3d32_vcycles(self._h, count, P(norms)))
         return norms
+
+
+class DistSolver32:
+    """`Solver32` on i-slabs: rank `rank` of `nranks` (one process per GPU, RCCL), or -- unique_id=None -- all ranks
+    virtual in this process on one GPU (loopback transport)."""
+
+    def __init__(self, coarse_pts, num_levels, smooth_iters, omega=6.0 / 7.0, rank=0, nranks=1, unique_id=None, device=0,
+                 grid_length=1.0):
+        self.L = lib()
+        self._h = C.c_void_p()
+        uid = None if unique_id is None else C.c_char_p(bytes(unique_id))
+        check(self.L.mg3d32_dist_create(coarse_pts, num_levels, smooth_iters, omega, grid_length, rank, nranks, uid,
+                                        device, C.byref(self._h)))
+        self.c, self.num_levels, self.nu, self.rank, self.nranks = coarse_pts, num_levels, smooth_iters, rank, nranks
+        self.N = (coarse_pts - 1) * (1 << (num_levels - 1)) + 1
+        self.first_level = self.L.mg3d32_dist_first_level(self._h)
+        self.halo = self.L.mg3d32_dist_halo(self._h)
+
+    def close(self):
+        if self._h:
+            check(self.L.mg3d32_dist_destroy(self._h))
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def level_n(self, level):
+        return (self.c - 1) * (1 << level) + 1
+
+    def comm_info(self):
+        n, dev = C.c_int(0), C.c_int(0)
+        check(self.L.mg3d32_dist_comm_info(self._h, C.byref(n), C.byref(dev)))
+        return n.value, dev.value
+
+    def upload(self, field, level, host_full):
+        host_full = np.ascontiguousarray(host_full, dtype=np.float32).reshape(-1)
+        assert host_full.size == self.level_n(level) ** 3
+        check(self.L.mg3d32_dist_upload(self._h, field, level, PF(host_full)))
+
+    def download(self, field, level, out=None):
+        out = np.zeros(self.level_n(level) ** 3, dtype=np.float32) if out is None else out
+        check(self.L.mg3d32_dist_download(self._h, field, level, PF(out)))
+        return out
+
+    def zero(self, field, level):
+        check(self.L.mg3d32_dist_zero(self._h, field, level))
+
+    def fill_boundary(self, field, level):
+        check(self.L.mg3d32_dist_fill_boundary(self._h, field, level))
+
+    def setup_test_problem(self, fmg=False):
+        """As Solver32.setup_test_problem, every rank on its slab."""
+        top = self.num_levels - 1
+        for l in range(self.num_levels):
+            for f in (MG3D_U, MG3D_D, MG3D_R):
+                self.zero(f, l)
+        if fmg:
+            for l in range(self.num_levels):
+                self.fill_boundary(MG3D_D, l)
+            check(self.L.mg3d32_dist_fmg_initialize(self._h))
+        else:
+            self.fill_boundary(MG3D_U, top)
+            self.fill_boundary(MG3D_D, top)
+
+    def vcycles(self, count):
+        norms = np.zeros(count)
+        check(self.L.mg3d32_dist_vcycles(self._h, count, P(norms)))
+        return norms
+
+    def sync(self):
+        check(self.L.mg3d32_dist_sync(self._h))

@@ -38,33 +38,19 @@
             return rc_;     \
     } while (0)
 
-struct Level32 {
-    Geom g; /* pitch and plane in floats */
-    double hd; /* spacing as the hierarchy defines it (double); h = (float)hd */
-    float h, hSq, invHsq;
-    size_t elems;
-    float *f[3]; /* u, d, r */
-    float *alt;  /* the smoother's second buffer */
-};
-
-struct mg3d32_ctx {
-    int c, L, iters;
-    float omega;
-    std::vector<Level32> lv;
-    mg3d_ctx *coarse64; /* one-level double context: LU factors and the direct solve */
-    hipStream_t stream;
-    double *partials, *sumsq, *h_sumsq;
-    int sumsq_slots;
-    /* MG3D_F32_NO_PAIRS=1 / MG3D_F32_NO_FUSE=1, read when the context is created: one launch per sweep / per
-     * operator instead of the paired and fused kernels (same bits; tests/test_gpu_f32.py) */
-    bool no_pairs, no_fuse;
-};
+#include "mg3d_f32_int.h"
 
 static inline int pitch32(int nk) { return (nk + 31) & ~31; }
 
 __device__ __forceinline__ long long gidx32(const Geom &g, int i, int j, int k)
 {
     return g.plane * i + (long long)g.pitch * j + k;
+}
+/* local plane q may be updated: not a physical boundary plane, not the outermost plane of an i-slab (which has no
+ * neighbour on one side).  On a single domain (ig0 = 0, ni = N) simply 1 <= q <= N-2. */
+__device__ __forceinline__ bool plane_upd(const Geom &g, int q)
+{
+    return q >= 1 && q <= g.ni - 2 && g.ig0 + q >= 1 && g.ig0 + q <= g.N - 2;
 }
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
@@ -99,7 +85,7 @@ __global__ void __launch_bounds__(256) jacobi32_kernel(Geom g, const float *__re
     for (int i = i0; i < i1; i++, p += g.plane) {
         const float4 above = i + 1 < g.ni ? ld4(vin + p + g.plane) : zero;
         float4 out = here;
-        if (jin && i >= 1 && i <= g.ni - 2) {
+        if (jin && plane_upd(g, i)) {
             const float4 jm = ld4(vin + p - g.pitch), jp = ld4(vin + p + g.pitch), dd = ld4(d + p);
             const float left = k0 > 0 ? vin[p - 1] : 0.f;
             const float right = k0 + 4 < g.nk ? vin[p + 4] : 0.f;
@@ -173,7 +159,7 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
                                                           const float *__restrict__ d, float *__restrict__ vout,
                                                           float hSq, float sixth, float omega, float invHsq,
                                                           double *__restrict__ partials, int chunk, Geom gc,
-                                                          const float *__restrict__ ec)
+                                                          const float *__restrict__ ec, int acc_lo, int acc_hi)
 {
     constexpr int OUT_ROWS = NORM ? J2N_OUT_ROWS : J2_OUT_ROWS, R0 = NORM ? 3 : 2;
     __shared__ float cpl[PRO ? 3 : 1][PRO ? CP_ROWS : 1][PRO ? CP_COLS : 1];
@@ -221,13 +207,14 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
                 (&cpl[sl][0][0])[idx] = buf[t];
         }
     };
-    /* v_in(plane i) = u + P(ec): the staged planes cover coarse_lo(i) and, for odd i, the one above */
+    /* v_in(plane i) = u + P(ec): the staged planes cover coarse_lo(i) and, for odd i, the one above.  Parity and
+     * parents follow the GLOBAL plane index ig0 + i; cl is the local index of the lower coarse parent plane. */
     auto load_in = [&](int i) {
         float4 v = load(vin, i);
         if constexpr (PRO) {
             if (in_dom && i >= 0 && i < g.ni) {
-                const int oi = i & 1, oj = j & 1;
-                const int cl = (i - oi) / 2, lr = (j - oj) / 2 - jcb, lc = 2 * lane;
+                const int oi = (g.ig0 + i) & 1, oj = j & 1;
+                const int cl = (g.ig0 + i - oi) / 2 - gc.ig0, lr = (j - oj) / 2 - jcb, lc = 2 * lane;
                 const int s0 = slot_of(cl), s1 = slot_of(cl + 1);
                 float E0[2][3], E1[2][3];
 #pragma unroll
@@ -279,7 +266,8 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
     };
     int have_hi = 0;
     if constexpr (PRO) {
-        const int lo = (a0 - 2 - ((a0 - 2) & 1)) / 2; /* floor((a0-2)/2) */
+        const int gl = g.ig0 + a0 - 2;
+        const int lo = (gl - (gl & 1)) / 2 - gc.ig0; /* floor(global plane / 2), as a local coarse index */
         float buf[2];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -300,8 +288,8 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
         const float4 d1 = load(d, a - 1);
         float cbuf[2];
         bool stage_new = false;
-        if constexpr (PRO) { /* plane a+1 needs coarse planes up to ceil((a+1)/2) */
-            stage_new = (a + 2) / 2 > have_hi && a + 1 >= 0; /* a+1 >= 0: (a+2)/2 == ceil((a+1)/2) */
+        if constexpr (PRO) { /* plane a+1 (global G) needs coarse planes up to ceil(G/2) */
+            stage_new = a + 1 >= 0 && (g.ig0 + a + 2) / 2 - gc.ig0 > have_hi; /* G >= 0: (G+1)/2 == ceil(G/2) */
             if (stage_new)
                 coarse_fetch(have_hi + 1, cbuf);
         }
@@ -327,7 +315,7 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
             const float left = __shfl_up(in_c.w, 1, 64), right = __shfl_down(in_c.x, 1, 64);
             const int q = a - 1;
             s_new = jacobi_pt4(in_m, in_p, ijm, ijp, left, in_c, right, d1, hSq, sixth, omega,
-                               row_upd && q >= 1 && q <= g.ni - 2, k0, g.nk);
+                               row_upd && plane_upd(g, q), k0, g.nk);
         }
         s1b[r][lane] = s_new;
         /* sweep 2 of plane a-2 */
@@ -336,7 +324,7 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
             const int q = a - 2;
             const float left = __shfl_up(s_c.w, 1, 64), right = __shfl_down(s_c.x, 1, 64);
             o = jacobi_pt4(s_m, s_new, sjm, sjp, left, s_c, right, d2, hSq, sixth, omega,
-                           row_upd && q >= 1 && q <= g.ni - 2, k0, g.nk);
+                           row_upd && plane_upd(g, q), k0, g.nk);
             if (own && q >= i0 && q < i1)
                 st4(vout + g.plane * q + col, o);
         }
@@ -345,7 +333,7 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
             /* residual of plane a-3 (mg_3d.h:819-821) */
             const int q = a - 3;
             const float left = __shfl_up(o_c.w, 1, 64), right = __shfl_down(o_c.x, 1, 64);
-            if (own && row_upd && q >= i0 && q < i1 && q >= 1 && q <= g.ni - 2) {
+            if (own && row_upd && q >= i0 && q < i1 && plane_upd(g, q) && q >= acc_lo && q < acc_hi) {
                 const float hv[6] = {left, o_c.x, o_c.y, o_c.z, o_c.w, right};
                 const float bl[4] = {o_m.x, o_m.y, o_m.z, o_m.w}, ab[4] = {o.x, o.y, o.z, o.w};
                 const float jmv[4] = {ojm.x, ojm.y, ojm.z, ojm.w}, jpv[4] = {ojp.x, ojp.y, ojp.z, ojp.w};
@@ -390,12 +378,13 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
 __global__ void __launch_bounds__(256) residual32_kernel(Geom g, const float *__restrict__ v,
                                                          const float *__restrict__ d, float invHsq,
                                                          float *__restrict__ res, double *__restrict__ partials,
-                                                         int chunk)
+                                                         int chunk, int p_lo, int p_hi, int acc_lo, int acc_hi)
 {
+    /* planes [p_lo, p_hi): all of them updatable (the launcher clips); the norm takes those in [acc_lo, acc_hi) */
     __shared__ double lds4[4];
     const int k0 = 4 * (blockIdx.x * 64 + threadIdx.x);
     const int j = blockIdx.y * 4 + threadIdx.y;
-    const int i0 = 1 + blockIdx.z * chunk, i1 = min(i0 + chunk, g.ni - 1);
+    const int i0 = p_lo + blockIdx.z * chunk, i1 = min(i0 + chunk, p_hi);
     double acc = 0.;
     if (k0 < g.nk && j >= 1 && j <= g.nj - 2) {
         long long p = gidx32(g, i0, j, k0);
@@ -415,7 +404,7 @@ __global__ void __launch_bounds__(256) residual32_kernel(Geom g, const float *__
                 const int k = k0 + c;
                 const float s = sum6(bl[c], ab[c], jmv[c], jpv[c], hv[c], hv[c + 2]) - 6 * hv[c + 1];
                 df[c] = dv[c] - invHsq * s;
-                if (k >= 1 && k <= g.nk - 2)
+                if (k >= 1 && k <= g.nk - 2 && i >= acc_lo && i < acc_hi)
                     acc += (double)df[c] * (double)df[c];
             }
             if (res) { /* interior only (mg_3d.h:824-825): one 16-byte store unless the vector touches a face */
@@ -444,13 +433,15 @@ __global__ void __launch_bounds__(256) residual32_kernel(Geom g, const float *__
 /* restrictResidual (mg_3d.h:844-998) in binary32: faces by injection, interior by the 27-point sum in
  * ti, tj, tk order starting from 0 */
 __global__ void __launch_bounds__(256) restrict32_kernel(Geom gf, const float *__restrict__ r, Geom gc,
-                                                         float *__restrict__ dc)
+                                                         float *__restrict__ dc, int c_lo)
 {
-    const int kc = blockIdx.x * 64 + threadIdx.x, jc = blockIdx.y * 4 + threadIdx.y, ic = blockIdx.z;
+    /* coarse plane ic (local) sits under the fine plane with the doubled GLOBAL index */
+    const int kc = blockIdx.x * 64 + threadIdx.x, jc = blockIdx.y * 4 + threadIdx.y, ic = c_lo + blockIdx.z;
     if (kc >= gc.nk || jc >= gc.nj)
         return;
-    const long long pf = gidx32(gf, 2 * ic, 2 * jc, 2 * kc);
-    const bool face = ic == 0 || ic == gc.ni - 1 || jc == 0 || jc == gc.nj - 1 || kc == 0 || kc == gc.nk - 1;
+    const int icg = gc.ig0 + ic;
+    const long long pf = gidx32(gf, 2 * icg - gf.ig0, 2 * jc, 2 * kc);
+    const bool face = icg == 0 || icg == gc.N - 1 || jc == 0 || jc == gc.nj - 1 || kc == 0 || kc == gc.nk - 1;
     float val;
     if (face) {
         val = r[pf];
@@ -477,15 +468,17 @@ __global__ void __launch_bounds__(256) restrict32_kernel(Geom gf, const float *_
  * (mg_3d.h:973-989).  Coarse faces (injection) are left to restrict32_faces_kernel. */
 __global__ void __launch_bounds__(1024) residual_restrict32_kernel(Geom g, const float *__restrict__ v,
                                                                    const float *__restrict__ d, float invHsq, Geom gc,
-                                                                   float *__restrict__ dc, int cchunk)
+                                                                   float *__restrict__ dc, int cchunk, int c_lo, int c_hi)
 {
     __shared__ float4 inp[2][J2_ROWS][64];
     __shared__ float rb[2][J2_ROWS][256];
     const int lane = threadIdx.x, r = threadIdx.y, tid = r * 64 + lane;
     const int jt0 = (int)blockIdx.y * J2_OUT_ROWS - 2, kt0 = (int)blockIdx.x * J2_OUT_COLS - 4;
     const int j = jt0 + r, k0 = kt0 + 4 * lane;
-    /* coarse planes [c0, c1) of this block; fine planes 2c0-1 .. 2c1-1 are needed */
-    const int c0 = max(1, (int)blockIdx.z * cchunk), c1 = min((int)(blockIdx.z + 1) * cchunk, gc.ni - 1);
+    /* coarse planes [c0, c1) of this block, local indices out of the launch's [c_lo, c_hi) (interior coarse planes
+     * only); the fine plane under coarse plane c has the doubled GLOBAL index: local qf(c) = 2 (gc.ig0 + c) - g.ig0,
+     * and planes qf(c0)-1 .. qf(c1)-1 are needed */
+    const int c0 = c_lo + (int)blockIdx.z * cchunk, c1 = min(c0 + cchunk, c_hi);
     if (c0 >= c1)
         return;
     const bool in_dom = j >= 0 && j < g.nj && k0 >= 0 && k0 < g.nk;
@@ -500,7 +493,7 @@ __global__ void __launch_bounds__(1024) residual_restrict32_kernel(Geom g, const
     const bool cown = tid < 6 * 124 && jc >= 1 && jc <= gc.nj - 2 && kc >= 1 && kc <= gc.nk - 2;
     const int fr = 2 + 2 * jcl, fc = 4 + 2 * kcl; /* centre in tile coordinates */
     float accA = 0.f, accB = 0.f; /* coarse plane being completed / the one after it */
-    const int q0 = 2 * c0 - 1, q1 = 2 * c1 - 1; /* fine planes q0 .. q1 inclusive */
+    const int q0 = 2 * (gc.ig0 + c0) - g.ig0 - 1, q1 = 2 * (gc.ig0 + c1) - g.ig0 - 1; /* fine planes q0 .. q1 inclusive */
     float4 in_m = load(v, q0 - 1), in_c = load(v, q0);
     for (int q = q0; q <= q1; q++) {
         const float4 in_p = load(v, q + 1);
@@ -528,7 +521,8 @@ __global__ void __launch_bounds__(1024) residual_restrict32_kernel(Geom g, const
         __syncthreads();
         if (cown) {
             /* this plane's nine products, tj then tk ascending; the i-weight is 1/2 on the centre plane, else 1/4 */
-            const float wi = (q & 1) ? 0.25f : 0.5f;
+            const int qg = g.ig0 + q; /* the i-weight and the coarse plane follow the global index */
+            const float wi = (qg & 1) ? 0.25f : 0.5f;
             float p9[9];
 #pragma unroll
             for (int tj = 0; tj < 3; tj++)
@@ -537,12 +531,12 @@ __global__ void __launch_bounds__(1024) residual_restrict32_kernel(Geom g, const
                     const float w = (wi * (tj == 1 ? 0.5f : 0.25f)) * (tk == 1 ? 0.5f : 0.25f);
                     p9[tj * 3 + tk] = rb[pb][fr - 1 + tj][fc - 1 + tk] * w;
                 }
-            if (q & 1) {
-                /* completes coarse plane (q-1)/2, starts coarse plane (q+1)/2 */
+            if (qg & 1) {
+                /* completes coarse plane (qg-1)/2, starts coarse plane (qg+1)/2 */
 #pragma unroll
                 for (int t = 0; t < 9; t++)
                     accA += p9[t];
-                const int ic = (q - 1) / 2;
+                const int ic = (qg - 1) / 2 - gc.ig0;
                 if (ic >= c0 && ic < c1)
                     dc[gc.plane * ic + (long long)gc.pitch * jc + kc] = accA;
                 accB = 0.f;
@@ -563,26 +557,30 @@ __global__ void __launch_bounds__(1024) residual_restrict32_kernel(Geom g, const
 
 /* injection on the six coarse faces (mg_3d.h:879-958) from the stored r (whose boundary entries nothing writes) */
 __global__ void __launch_bounds__(256) restrict32_faces_kernel(Geom gf, const float *__restrict__ r, Geom gc,
-                                                               float *__restrict__ dc)
+                                                               float *__restrict__ dc, int c_lo, int c_hi)
 {
+    /* the face points among the local coarse planes [c_lo, c_hi); i-faces only where the slab holds the physical one */
     const int b = blockIdx.x * 64 + threadIdx.x, a = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
-    if (a >= gc.ni || b >= gc.ni)
+    const int m = gc.nj; /* nj == nk == N */
+    if (a >= m || b >= m)
         return;
     int ic, jc, kc;
     if (f < 2) {
-        ic = f == 0 ? 0 : gc.ni - 1;
+        ic = (f == 0 ? 0 : gc.N - 1) - gc.ig0;
         jc = a;
         kc = b;
     } else if (f < 4) {
-        ic = a;
+        ic = a - gc.ig0; /* a runs over global planes */
         jc = f == 2 ? 0 : gc.nj - 1;
         kc = b;
     } else {
-        ic = a;
+        ic = a - gc.ig0;
         jc = b;
         kc = f == 4 ? 0 : gc.nk - 1;
     }
-    dc[gidx32(gc, ic, jc, kc)] = r[gidx32(gf, 2 * ic, 2 * jc, 2 * kc)];
+    if (ic < c_lo || ic >= c_hi)
+        return;
+    dc[gidx32(gc, ic, jc, kc)] = r[gidx32(gf, 2 * (gc.ig0 + ic) - gf.ig0, 2 * jc, 2 * kc)];
 }
 
 /* prolongateAndCorrectError (mg_3d.h:1000-1145) in binary32, cell form: a thread owns the 2 x 2 fine points
@@ -609,7 +607,7 @@ __global__ void __launch_bounds__(256) prolong32_kernel(Geom gc, const float *__
         E[1][1] = pl[c11];
     };
     for (int i = i_beg; i < i_end; i++) {
-        const int oi = i & 1, il = (i - oi) / 2;
+        const int oi = (gf.ig0 + i) & 1, il = (gf.ig0 + i - oi) / 2 - gc.ig0; /* global parity, local coarse plane */
         if (have != il) {
             if (have + 1 == il) {
                 E0[0][0] = E1[0][0];
@@ -663,9 +661,10 @@ __global__ void __launch_bounds__(256) fill_boundary32_kernel(Geom g, float *__r
     const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, i = blockIdx.z;
     if (k >= g.nk || j >= g.nj)
         return;
-    if (!(i == 0 || i == g.ni - 1 || j == 0 || j == g.nj - 1 || k == 0 || k == g.nk - 1))
+    const int ig = g.ig0 + i;
+    if (!(ig == 0 || ig == g.N - 1 || j == 0 || j == g.nj - 1 || k == 0 || k == g.nk - 1))
         return;
-    const double x = i * h, y = j * h, z = k * h;
+    const double x = ig * h, y = j * h, z = k * h;
     v[gidx32(g, i, j, k)] = (float)(x * x - 2 * y * y + z * z);
 }
 
@@ -712,6 +711,13 @@ extern "C" int mg3d32_destroy(mg3d32_ctx *ctx)
 extern "C" int mg3d32_create(int coarse_pts, int num_levels, int smooth_iters, double omega, double grid_length,
                              mg3d32_ctx **out)
 {
+    return mg3d32_create_slabs(coarse_pts, num_levels, smooth_iters, omega, grid_length, num_levels, nullptr, nullptr, 0,
+                               nullptr, out);
+}
+
+int mg3d32_create_slabs(int coarse_pts, int num_levels, int smooth_iters, double omega, double grid_length,
+                        int first_slab, const int *glo, const int *ghi, int halo, hipStream_t share, mg3d32_ctx **out)
+{
     if (!out || coarse_pts < 3 || coarse_pts > 11 || num_levels < 1 || num_levels > 24 || smooth_iters < 0 ||
         !(omega > 0.) || !(grid_length > 0.))
         return fail(MG3D_ERR_ARG, "mg3d32_create: bad arguments");
@@ -731,6 +737,13 @@ extern "C" int mg3d32_create(int coarse_pts, int num_levels, int smooth_iters, d
     if (rc != MG3D_OK) {
         delete ctx;
         return rc;
+    }
+    ctx->own_stream = true;
+    if (share) { /* several contexts of one process (virtual ranks) run on one ordered stream */
+        (void)hipStreamDestroy(ctx->coarse64->stream);
+        ctx->coarse64->stream = share;
+        ctx->coarse64->own_stream = false;
+        ctx->own_stream = false;
     }
     ctx->stream = ctx->coarse64->stream;
     const long long finest = ((long long)(coarse_pts - 1) << (num_levels - 1)) + 1;
@@ -760,13 +773,22 @@ extern "C" int mg3d32_create(int coarse_pts, int num_levels, int smooth_iters, d
         const int N = (coarse_pts - 1) * (1 << l) + 1;
         lev.g.ni = lev.g.nj = lev.g.nk = lev.g.N = N;
         lev.g.ig0 = 0;
+        lev.own_lo = 0;
+        lev.own_hi = N;
+        if (l >= first_slab) { /* owned planes [glo, ghi) + `halo` planes towards every neighbour */
+            const int h_lo = glo[l] > 0 ? halo : 0, h_hi = ghi[l] < N ? halo : 0;
+            lev.g.ig0 = glo[l] - h_lo;
+            lev.g.ni = (ghi[l] - glo[l]) + h_lo + h_hi;
+            lev.own_lo = h_lo;
+            lev.own_hi = h_lo + (ghi[l] - glo[l]);
+        }
         lev.g.pitch = pitch32(N);
         lev.g.plane = (long long)lev.g.pitch * N;
         lev.hd = hs[l];
         lev.h = (float)hs[l];
         lev.hSq = lev.h * lev.h;
         lev.invHsq = 1.0f / (lev.h * lev.h);
-        lev.elems = (size_t)lev.g.plane * N;
+        lev.elems = (size_t)lev.g.plane * lev.g.ni;
         for (int k = 0; k < 3; k++)
             lev.f[k] = nullptr;
         lev.alt = nullptr;
@@ -840,13 +862,12 @@ static int chunk_for(int planes, long long blocks_per_plane, long long want = 40
     return chunk;
 }
 
-static void e_prolong(mg3d32_ctx *ctx, int level);
 
 /* `iters` sweeps.  norm_slot >= 0: the caller wants ||d - A u|| of the result in sumsq[norm_slot]; returns true when
  * the last launch delivered it (paired sweep with the residual as third stage), false when a residual launch
  * still has to follow.  prolong_first: u += P(u of the next coarser level) before the first sweep (mg_3d.h:1331),
  * folded into the first paired launch when there is one. */
-static bool e_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot = -1, bool prolong_first = false)
+bool e32_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot, bool prolong_first)
 {
     Level32 &l = ctx->lv[level];
     const int gx = ((l.g.nk + 3) / 4 + 63) / 64, gy = (l.g.nj + 3) / 4;
@@ -861,7 +882,7 @@ static bool e_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot = -1, 
     };
     const bool pairs = !no_pairs && l.g.N >= 33 && iters >= 2;
     if (prolong_first && !(pairs && !no_fuse))
-        e_prolong(ctx, level);
+        e32_prolong(ctx, level);
     if (pairs) { /* sweeps in pairs: one pass over HBM for two */
         const int px = (l.g.nk + J2_OUT_COLS - 1) / J2_OUT_COLS;
         for (; it + 2 <= iters; it += 2) {
@@ -879,7 +900,7 @@ static bool e_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot = -1, 
             double *part = with_norm ? ctx->partials : nullptr;
 #define J2_LAUNCH(NORM, PRO)                                                                                       \
     hipLaunchKernelGGL((jacobi32x2_kernel<NORM, PRO>), grid, block, 0, ctx->stream, l.g, l.f[MG3D_U], l.f[MG3D_D], \
-                       l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, l.invHsq, part, ch, gc, ec)
+                       l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, l.invHsq, part, ch, gc, ec, l.own_lo, l.own_hi)
             if (with_norm && with_pro)
                 J2_LAUNCH(true, true);
             else if (with_norm)
@@ -905,45 +926,60 @@ static bool e_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot = -1, 
     return normed;
 }
 
-static void e_residual(mg3d32_ctx *ctx, int level, bool store, int slot)
+void e32_residual(mg3d32_ctx *ctx, int level, bool store, int slot)
 {
     Level32 &l = ctx->lv[level];
-    if (l.g.N < 3) {
+    /* planes to form: the owned ones plus one on either side (a stored r is restricted from there), clipped to the
+     * updatable planes; the norm takes the owned ones */
+    int p_lo = l.own_lo - 1 > 1 ? l.own_lo - 1 : 1, p_hi = l.own_hi + 1 < l.g.ni - 1 ? l.own_hi + 1 : l.g.ni - 1;
+    if (p_hi > l.g.N - 1 - l.g.ig0)
+        p_hi = l.g.N - 1 - l.g.ig0;
+    if (l.g.N < 3 || p_hi <= p_lo) {
         (void)hipMemsetAsync(ctx->sumsq + slot, 0, sizeof(double), ctx->stream);
         return;
     }
-    const int gx = ((l.g.nk + 3) / 4 + 63) / 64, gy = (l.g.nj + 3) / 4;
-    int chunk = chunk_for(l.g.ni - 2, (long long)gx * gy);
-    while ((long long)gx * gy * ((l.g.ni - 2 + chunk - 1) / chunk) > MG3D_MAX_PARTIALS)
+    const int gx = ((l.g.nk + 3) / 4 + 63) / 64, gy = (l.g.nj + 3) / 4, np = p_hi - p_lo;
+    int chunk = chunk_for(np, (long long)gx * gy);
+    while ((long long)gx * gy * ((np + chunk - 1) / chunk) > MG3D_MAX_PARTIALS)
         chunk *= 2;
-    const int gz = (l.g.ni - 2 + chunk - 1) / chunk;
+    const int gz = (np + chunk - 1) / chunk;
     hipLaunchKernelGGL(residual32_kernel, dim3(gx, gy, gz), dim3(64, 4, 1), 0, ctx->stream, l.g, l.f[MG3D_U],
-                       l.f[MG3D_D], l.invHsq, store ? l.f[MG3D_R] : nullptr, ctx->partials, chunk);
+                       l.f[MG3D_D], l.invHsq, store ? l.f[MG3D_R] : nullptr, ctx->partials, chunk, p_lo, p_hi, l.own_lo,
+                       l.own_hi);
     k_fold(ctx->partials, gx * gy * gz, ctx->sumsq + slot, ctx->stream);
 }
 
-static void e_restrict(mg3d32_ctx *ctx, int level)
+void e32_restrict(mg3d32_ctx *ctx, int level)
 {
     Level32 &lf = ctx->lv[level], &lc = ctx->lv[level - 1];
-    hipLaunchKernelGGL(restrict32_kernel, dim3((lc.g.nk + 63) / 64, (lc.g.nj + 3) / 4, lc.g.ni), dim3(64, 4, 1), 0,
-                       ctx->stream, lf.g, lf.f[MG3D_R], lc.g, lc.f[MG3D_D]);
+    hipLaunchKernelGGL(restrict32_kernel, dim3((lc.g.nk + 63) / 64, (lc.g.nj + 3) / 4, lc.own_hi - lc.own_lo),
+                       dim3(64, 4, 1), 0, ctx->stream, lf.g, lf.f[MG3D_R], lc.g, lc.f[MG3D_D], lc.own_lo);
 }
 
-static void e_residual_restrict(mg3d32_ctx *ctx, int level)
+void e32_residual_restrict(mg3d32_ctx *ctx, int level, int c_lo, int c_hi)
 {
     Level32 &lf = ctx->lv[level], &lc = ctx->lv[level - 1];
+    if (c_lo < 0) { /* the coarse planes this context owns */
+        c_lo = lc.own_lo;
+        c_hi = lc.own_hi;
+    }
+    /* the 27-point sum on the interior coarse planes, injection on the faces (mg_3d.h:879-958) */
+    const int i_lo = c_lo > 1 - lc.g.ig0 ? c_lo : 1 - lc.g.ig0, i_hi = c_hi < lc.g.N - 1 - lc.g.ig0 ? c_hi : lc.g.N - 1 - lc.g.ig0;
     const int px = (lf.g.nk + J2_OUT_COLS - 1) / J2_OUT_COLS, py = (lf.g.nj + J2_OUT_ROWS - 1) / J2_OUT_ROWS;
-    int cch = 64; /* coarse planes per block */
-    while (cch > 4 && (long long)px * py * ((lc.g.ni + cch - 1) / cch) < 1024)
-        cch /= 2;
-    hipLaunchKernelGGL(residual_restrict32_kernel, dim3(px, py, (lc.g.ni + cch - 1) / cch), dim3(64, J2_ROWS, 1), 0,
-                       ctx->stream, lf.g, lf.f[MG3D_U], lf.f[MG3D_D], lf.invHsq, lc.g, lc.f[MG3D_D], cch);
-    const int m = lc.g.ni;
+    if (i_hi > i_lo) {
+        const int nc = i_hi - i_lo;
+        int cch = 64; /* coarse planes per block */
+        while (cch > 4 && (long long)px * py * ((nc + cch - 1) / cch) < 1024)
+            cch /= 2;
+        hipLaunchKernelGGL(residual_restrict32_kernel, dim3(px, py, (nc + cch - 1) / cch), dim3(64, J2_ROWS, 1), 0,
+                           ctx->stream, lf.g, lf.f[MG3D_U], lf.f[MG3D_D], lf.invHsq, lc.g, lc.f[MG3D_D], cch, i_lo, i_hi);
+    }
+    const int m = lc.g.N;
     hipLaunchKernelGGL(restrict32_faces_kernel, dim3((m + 63) / 64, (m + 3) / 4, 6), dim3(64, 4, 1), 0, ctx->stream,
-                       lf.g, lf.f[MG3D_R], lc.g, lc.f[MG3D_D]);
+                       lf.g, lf.f[MG3D_R], lc.g, lc.f[MG3D_D], c_lo, c_hi);
 }
 
-static void e_prolong(mg3d32_ctx *ctx, int level)
+void e32_prolong(mg3d32_ctx *ctx, int level)
 {
     Level32 &lf = ctx->lv[level], &lc = ctx->lv[level - 1];
     const int gx = ((lf.g.nk + 1) / 2 + 63) / 64, gy = ((lf.g.nj + 1) / 2 + 3) / 4;
@@ -952,7 +988,7 @@ static void e_prolong(mg3d32_ctx *ctx, int level)
                        lc.g, lc.f[MG3D_U], lf.g, lf.f[MG3D_U], chunk);
 }
 
-static int e_coarse_solve(mg3d32_ctx *ctx)
+int e32_coarse_solve(mg3d32_ctx *ctx)
 {
     Level32 &l0 = ctx->lv[0];
     Level &c0 = ctx->coarse64->lv[0];
@@ -963,7 +999,7 @@ static int e_coarse_solve(mg3d32_ctx *ctx)
     return MG3D_OK;
 }
 
-static void e_fill_boundary(mg3d32_ctx *ctx, int field, int level)
+void e32_fill_boundary(mg3d32_ctx *ctx, int field, int level)
 {
     Level32 &l = ctx->lv[level];
     hipLaunchKernelGGL(fill_boundary32_kernel, dim3((l.g.nk + 63) / 64, (l.g.nj + 3) / 4, l.g.ni), dim3(64, 4, 1), 0,
@@ -979,26 +1015,26 @@ static int launch_ok32(const char *who)
 }
 
 /* the V-cycle of mg_3d.h:1242-1362 with the Jacobi smoother; the level's norm lands in sumsq[slot] */
-static int e_vcycle(mg3d32_ctx *ctx, int q, int slot)
+int e32_vcycle(mg3d32_ctx *ctx, int q, int slot)
 {
     if (q == 0)
-        return e_coarse_solve(ctx);
-    e_jacobi(ctx, q, ctx->iters);                       /* :1282 */
+        return e32_coarse_solve(ctx);
+    e32_jacobi(ctx, q, ctx->iters);                       /* :1282 */
     if (!ctx->no_fuse && ctx->lv[q].g.N >= 33) {
-        e_residual_restrict(ctx, q);                    /* :1294 + :1310, r not stored */
+        e32_residual_restrict(ctx, q);                    /* :1294 + :1310, r not stored */
     } else {
-        e_residual(ctx, q, true, ctx->sumsq_slots - 1); /* :1294 (its norm is dropped) */
-        e_restrict(ctx, q);                             /* :1310 */
+        e32_residual(ctx, q, true, ctx->sumsq_slots - 1); /* :1294 (its norm is dropped) */
+        e32_restrict(ctx, q);                             /* :1310 */
     }
     Level32 &lc = ctx->lv[q - 1];
     (void)hipMemsetAsync(lc.f[MG3D_U], 0, lc.elems * sizeof(float), ctx->stream); /* :1258 */
-    CHK(e_vcycle(ctx, q - 1, ctx->sumsq_slots - 1));    /* :1321 */
+    CHK(e32_vcycle(ctx, q - 1, ctx->sumsq_slots - 1));    /* :1321 */
     /* :1331 + :1341 + :1354; below the top level the reference drops the norm (:1320), so it is not formed there */
     const bool top = q == ctx->L - 1;
     if (ctx->iters == 0)
-        e_prolong(ctx, q);
-    if (!e_jacobi(ctx, q, ctx->iters, top ? slot : -1, ctx->iters > 0) && top)
-        e_residual(ctx, q, false, slot);
+        e32_prolong(ctx, q);
+    if (!e32_jacobi(ctx, q, ctx->iters, top ? slot : -1, ctx->iters > 0) && top)
+        e32_residual(ctx, q, false, slot);
     return MG3D_OK;
 }
 
@@ -1008,7 +1044,7 @@ extern "C" int mg3d32_smooth(mg3d32_ctx *ctx, int level, int iters)
     if (iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d32_smooth: negative sweep count");
     if (ctx->lv[level].g.N >= 3)
-        e_jacobi(ctx, level, iters);
+        e32_jacobi(ctx, level, iters);
     return launch_ok32("mg3d32_smooth");
 }
 
@@ -1025,7 +1061,7 @@ static int norm_out(mg3d32_ctx *ctx, int slot, double *norm)
 extern "C" int mg3d32_residual(mg3d32_ctx *ctx, int level, int store, double *norm)
 {
     CHK(check32(ctx, 0, level, "mg3d32_residual"));
-    e_residual(ctx, level, store != 0, 0);
+    e32_residual(ctx, level, store != 0, 0);
     CHK(launch_ok32("mg3d32_residual"));
     return norm_out(ctx, 0, norm);
 }
@@ -1035,7 +1071,7 @@ extern "C" int mg3d32_restrict(mg3d32_ctx *ctx, int level)
     CHK(check32(ctx, 0, level, "mg3d32_restrict"));
     if (level < 1)
         return fail(MG3D_ERR_ARG, "mg3d32_restrict: no coarser level");
-    e_restrict(ctx, level);
+    e32_restrict(ctx, level);
     return launch_ok32("mg3d32_restrict");
 }
 
@@ -1044,7 +1080,7 @@ extern "C" int mg3d32_prolong(mg3d32_ctx *ctx, int level)
     CHK(check32(ctx, 0, level, "mg3d32_prolong"));
     if (level < 1)
         return fail(MG3D_ERR_ARG, "mg3d32_prolong: no coarser level");
-    e_prolong(ctx, level);
+    e32_prolong(ctx, level);
     return launch_ok32("mg3d32_prolong");
 }
 
@@ -1052,14 +1088,14 @@ extern "C" int mg3d32_coarse_solve(mg3d32_ctx *ctx)
 {
     if (!ctx)
         return fail(MG3D_ERR_ARG, "mg3d32_coarse_solve: NULL");
-    CHK(e_coarse_solve(ctx));
+    CHK(e32_coarse_solve(ctx));
     return launch_ok32("mg3d32_coarse_solve");
 }
 
 extern "C" int mg3d32_fill_boundary(mg3d32_ctx *ctx, int field, int level)
 {
     CHK(check32(ctx, field, level, "mg3d32_fill_boundary"));
-    e_fill_boundary(ctx, field, level);
+    e32_fill_boundary(ctx, field, level);
     return launch_ok32("mg3d32_fill_boundary");
 }
 
@@ -1079,7 +1115,7 @@ extern "C" int mg3d32_vcycles(mg3d32_ctx *ctx, int count, double *norms)
     for (int done = 0; done < count;) {
         const int nb = count - done < slots ? count - done : slots;
         for (int c = 0; c < nb; c++)
-            CHK(e_vcycle(ctx, ctx->L - 1, c));
+            CHK(e32_vcycle(ctx, ctx->L - 1, c));
         CHK(launch_ok32("mg3d32_vcycles"));
         HIPCHK(hipMemcpyAsync(ctx->h_sumsq, ctx->sumsq, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1096,14 +1132,14 @@ extern "C" int mg3d32_fmg_initialize(mg3d32_ctx *ctx)
 {
     if (!ctx)
         return fail(MG3D_ERR_ARG, "mg3d32_fmg_initialize: NULL");
-    e_fill_boundary(ctx, MG3D_U, 0);     /* :780 */
-    CHK(e_coarse_solve(ctx));            /* :783 */
+    e32_fill_boundary(ctx, MG3D_U, 0);     /* :780 */
+    CHK(e32_coarse_solve(ctx));            /* :783 */
     for (int l = 1; l < ctx->L; l++) {
-        e_prolong(ctx, l);               /* :795 */
-        e_fill_boundary(ctx, MG3D_U, l); /* :798 */
+        e32_prolong(ctx, l);               /* :795 */
+        e32_fill_boundary(ctx, MG3D_U, l); /* :798 */
         Level32 &lc = ctx->lv[l - 1];
         HIPCHK(hipMemsetAsync(lc.f[MG3D_U], 0, lc.elems * sizeof(float), ctx->stream)); /* :801 */
-        CHK(e_vcycle(ctx, l, ctx->sumsq_slots - 1));                                    /* :804 */
+        CHK(e32_vcycle(ctx, l, ctx->sumsq_slots - 1));                                    /* :804 */
     }
     return launch_ok32("mg3d32_fmg_initialize");
 }

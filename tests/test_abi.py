@@ -129,3 +129,32 @@ def test_lu_division_sequence_is_exact(tmp_path):
     r = subprocess.run([exe, "20000000" if hw_fma else "300000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout
     assert "mismatches 0" in r.stdout
+
+
+def test_fp32_slab_partition_is_the_fp64_one_with_its_own_halo():
+    """The fp32 / Jacobi slab path (csrc/mg3d_f32_dist.hip) uses the same partition functions with H = nu + 2: owned
+    ranges tile every distributed level, cuts are even on the first distributed level and double per finer level
+    (coarse plane ic and fine plane 2 ic share an owner).  Pure host arithmetic, no GPU."""
+    L = M.lib()
+    for nu in (1, 2, 3):
+        assert L.mg3d32_slab_halo(nu) == nu + 2 and L.mg3d_slab_halo(nu) == 2 * nu + 2
+    c, levels, nu = 9, 8, 2
+    H = L.mg3d32_slab_halo(nu)
+    for P_ in (2, 3, 4, 8):
+        ld = L.mg3d_slab_first_level(c, levels, P_, H)
+        assert 1 <= ld < levels
+        prev = None
+        for lvl in range(ld, levels):
+            N = (c - 1) * (1 << lvl) + 1
+            cuts = []
+            for r in range(P_):
+                lo, hi = C.c_int(0), C.c_int(0)
+                assert L.mg3d_slab_owned(c, levels, P_, H, lvl, r, C.byref(lo), C.byref(hi)) == 0
+                cuts.append((lo.value, hi.value))
+            assert cuts[0][0] == 0 and cuts[-1][1] == N
+            assert all(cuts[r][1] == cuts[r + 1][0] for r in range(P_ - 1))
+            assert all(hi - lo >= max(16, H) for lo, hi in cuts)
+            assert all(lo % 2 == 0 for lo, _ in cuts)
+            if prev is not None:
+                assert [lo for lo, _ in cuts] == [2 * lo for lo, _ in prev]
+            prev = cuts

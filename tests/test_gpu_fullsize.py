@@ -108,3 +108,20 @@ def test_configs4_1025_cubed_fp32_fcycle(monkeypatch):
             assert _digest(s.download(MG3D_U, L - 1)) == digest, knob
         np.testing.assert_allclose(n2, n_ref, rtol=1e-12)
         monkeypatch.delenv(knob)
+
+
+def test_configs4_1025_cubed_fp32_on_8_slabs():
+    """configs[4] at its workload on 8 virtual ranks (loopback): F-cycle start + 2 V(2,2) cycles at 1025^3; the
+    assembled 4.3 GB solution has the digest of the single-domain one, norms to the summation order."""
+    c, L, nu = 9, 8, 2
+    with M.Solver32(c, L, nu) as s:
+        s.setup_test_problem(fmg=True)
+        want_n = s.vcycles(2)
+        want = _digest(s.download(MG3D_U, L - 1))
+    with M.DistSolver32(c, L, nu, nranks=8) as d:
+        assert d.halo == 4 and d.first_level == 4  # levels >= 129^3 distributed (16 planes per rank there)
+        d.setup_test_problem(fmg=True)
+        norms = d.vcycles(2)
+        got = _digest(d.download(MG3D_U, L - 1))
+    assert got == want
+    np.testing.assert_allclose(norms, want_n, rtol=1e-12, atol=0)
