@@ -132,6 +132,27 @@ enum {
 const char *mg3d_kernel_name(int kernel);
 int mg3d_kernel_time_get(mg3d_ctx *ctx, int level, int kernel, int *num_launches, double *seconds);
 
+/* ------------------------------------------------------------ mixed boundary conditions ("electrospray")
+ * The problem the reference was written for (mg_3d_bkup.c:12-18, 84-133, 739-778): Dirichlet patches on the two x
+ * faces -- a capillary disc and an extractor annulus -- and zero-gradient walls everywhere else, imposed by copying a
+ * freshly smoothed interior value onto the wall point behind it.  Carried by the live operators of mg_3d.h
+ * (csrc/mg3d_es.hip; parity unpinned: the original neither compiles nor is order-independent).  The context must have
+ * been created with grid_length == params->length. */
+typedef struct mg3d_es_params {
+    double length;                  /* side of the cube (GRID_LENGTH, mg_3d_bkup.c:12) */
+    double capillary_radius;        /* Dirichlet disc on x = 0 (:14) */
+    double extractor_inner_radius;  /* Dirichlet annulus on x = length (:15-16) */
+    double extractor_outer_radius;
+    double capillary_voltage;       /* (:17) */
+    double extractor_voltage;       /* (:18) */
+} mg3d_es_params;
+int mg3d_es_default_params(mg3d_es_params *p); /* the reference's #defines */
+/* host: the coarsest operator with zero-gradient rows on the walls (A zeroed by the caller, (N^3)^2 doubles) */
+void mg3d_es_coarse_matrix(double *A, int N, double h, const mg3d_es_params *p);
+int mg3d_es_setup(mg3d_ctx *ctx, const mg3d_es_params *p); /* zero fields, patches on the finest u, coarse LU */
+int mg3d_es_smooth(mg3d_ctx *ctx, int level, int post, int iters); /* red-black passes + ghost copies */
+int mg3d_es_vcycles(mg3d_ctx *ctx, int count, double *norms);
+
 /* ------------------------------------------------------------ several GPUs (i-slabs)
  * The reference splits every operator over the slowest index i between OpenMP threads (mg_3d.h:658-659);
  * here rank r of nranks (one process per GPU) owns a contiguous range of i-planes of every level large

@@ -114,6 +114,11 @@ SIGNATURES = {
     "mg3d32_coarse_solve": (C.c_int, [C.c_void_p]),
     "mg3d32_vcycles": (C.c_int, [C.c_void_p, C.c_int, dp]),
     "mg3d32_fmg_initialize": (C.c_int, [C.c_void_p]),
+    "mg3d_es_default_params": (C.c_int, [C.c_void_p]),
+    "mg3d_es_coarse_matrix": (None, [dp, C.c_int, C.c_double, C.c_void_p]),
+    "mg3d_es_setup": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mg3d_es_smooth": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mg3d_es_vcycles": (C.c_int, [C.c_void_p, C.c_int, dp]),
     "mg3d32_slab_halo": (C.c_int, [C.c_int]),
     "mg3d32_dist_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p,
                                      C.c_int, C.POINTER(C.c_void_p)]),
@@ -129,6 +134,18 @@ SIGNATURES = {
     "mg3d32_dist_fmg_initialize": (C.c_int, [C.c_void_p]),
     "mg3d32_dist_sync": (C.c_int, [C.c_void_p]),
 }
+
+
+class EsParams(C.Structure):
+    """mg3d_es_params: the mixed-boundary problem of mg_3d_bkup.c:12-18 (defaults = the reference's #defines)."""
+    _fields_ = [("length", C.c_double), ("capillary_radius", C.c_double), ("extractor_inner_radius", C.c_double),
+                ("extractor_outer_radius", C.c_double), ("capillary_voltage", C.c_double), ("extractor_voltage", C.c_double)]
+
+    @staticmethod
+    def default():
+        p = EsParams()
+        check(lib().mg3d_es_default_params(C.byref(p)))
+        return p
 
 
 def lib():
@@ -310,6 +327,20 @@ class Solver:
 
     def fmg_initialize(self):
         check(self.L.mg3d_fmg_initialize(self._h))
+
+    # -- the mixed-boundary ("electrospray") problem, csrc/mg3d_es.hip
+    def es_setup(self, params=None):
+        self.es = params or EsParams.default()
+        check(self.L.mg3d_es_setup(self._h, C.byref(self.es)))
+        return self.es
+
+    def es_smooth(self, level, post, iters):
+        check(self.L.mg3d_es_smooth(self._h, level, int(post), iters))
+
+    def es_vcycles(self, count):
+        norms = np.zeros(count)
+        check(self.L.mg3d_es_vcycles(self._h, count, P(norms)))
+        return norms
 
     def fill_boundary(self, field, level):
         check(self.L.mg3d_fill_boundary(self._h, field, level))

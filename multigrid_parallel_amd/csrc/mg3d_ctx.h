@@ -38,6 +38,9 @@ struct mg3d_ctx {
      * level l or d of level l-1.  faces_dirty[l] says the injection l -> l-1 has to be redone (set at creation, by
      * upload / zero of those fields); faces_always[l] after a raw device pointer to one of them was handed out. */
     std::vector<char> faces_dirty, faces_always;
+    /* the mixed-boundary problem of csrc/mg3d_es.hip, after mg3d_es_setup */
+    bool have_es;
+    mg3d_es_params es;
     bool fused; /* fused sweep kernel (default) or one launch per colour pass (MG3D_NO_FUSE=1) */
     int timing; /* 0 off, 1 every level, 2 finest level only */
     std::vector<StageTimer> timers; /* [L][MG3D_NUM_STAGES] */

@@ -201,6 +201,7 @@ static mg3d_ctx *ctx_new(int L, int iters)
     ctx->lv.resize(L);
     for (auto &l : ctx->lv)
         l.f[0] = l.f[1] = l.f[2] = l.alt = nullptr;
+    ctx->have_es = false;
     ctx->faces_dirty.assign(L, 1);
     ctx->faces_always.assign(L, 0);
     ctx->fused = true;

@@ -64,6 +64,40 @@ void mg3d_coarse_matrix(double *A, int N, double h)
             }
 }
 
+/* The coarsest operator of the mixed-boundary problem (csrc/mg3d_es.hip): constructCoarseMatrixA (identity rows on
+ * the boundary, mg_3d.h:179-185) except that a wall point -- a face point with an interior point in front of it that is
+ * not part of a Dirichlet patch -- gets the row  x_wall - x_front = b_wall, the zero-gradient condition the smoother
+ * imposes by its ghost copy (mg_3d_bkup.c:84-133).  The original pins every boundary point of the coarsest level
+ * (mg_3d_bkup.c:490-494), which leaves the cycle with a convergence factor of 0.93-0.96. */
+void mg3d_es_coarse_matrix(double *A, int N, double h, const mg3d_es_params *p)
+{
+    const long NN = (long)N * N, n = NN * N;
+    mg3d_coarse_matrix(A, N, h);
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++)
+            for (int k = 0; k < N; k++) {
+                const int fi = i == 0 || i == N - 1, fj = j == 0 || j == N - 1, fk = k == 0 || k == N - 1;
+                if (fi + fj + fk != 1)
+                    continue; /* interior, or an edge / corner (never read by the stencil) */
+                const long q = NN * i + (long)N * j + k;
+                long front;
+                if (fi) {
+                    const double ty = j * h - p->length / 2., tz = k * h - p->length / 2., rr = ty * ty + tz * tz;
+                    const int dirichlet = i == 0 ? rr <= p->capillary_radius * p->capillary_radius
+                                                 : (rr > p->extractor_inner_radius * p->extractor_inner_radius &&
+                                                    rr < p->extractor_outer_radius * p->extractor_outer_radius);
+                    if (dirichlet)
+                        continue;
+                    front = i == 0 ? q + NN : q - NN;
+                } else if (fj) {
+                    front = j == 0 ? q + N : q - N;
+                } else {
+                    front = k == 0 ? q + 1 : q - 1;
+                }
+                A[q * n + front] = -1.;
+            }
+}
+
 /* convertToLU_InPlace, gauss_elim.h:9-29: Doolittle, unit-lower, no pivoting,
  * row-major in place.  The multiplier z = a[k][i] / a[i][i] is formed as
  * a[k][i] * (1/a[i][i]) exactly as :17,:22 do.  Rows whose multiplier is an

@@ -58,6 +58,13 @@ def lib():
         L.orc32_coarse_solve.argtypes = [dp, C.c_int, fp, fp]
         L.orc32_run_problem.restype = C.c_double
         L.orc32_run_problem.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, dp, fp]
+        # the mixed-boundary ("electrospray") problem (oracle/mg3d_oracle_es.c, parity unpinned)
+        L.orc_es_fill.argtypes = [dp, C.c_int, C.c_double, C.c_void_p, C.c_double]
+        L.orc_es_smooth.argtypes = [dp, dp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p]
+        L.orc_es_ghost_all.argtypes = [dp, C.c_int, C.c_double, C.c_void_p]
+        L.orc_es_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, dp, dp, dp]
+        L.orc_es_dirichlet_x0.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
+        L.orc_es_dirichlet_xl.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
         L.orc_max_threads.restype = C.c_int
         L.orc_set_threads.argtypes = [C.c_int]
         _lib = L
@@ -89,3 +96,20 @@ def run_problem(c, L, nu, cycles, mode=0, want_u=True):
     init = C.c_double(0)
     secs = lib().orc_run_problem(c, L, nu, cycles, mode, P(norms), P(u) if want_u else None, C.byref(init))
     return norms, u, init.value, secs
+
+
+class EsParams(C.Structure):
+    """orc_es_params (same layout as the product's mg3d_es_params); defaults = mg_3d_bkup.c:12-18"""
+    _fields_ = [("length", C.c_double), ("capillary_radius", C.c_double), ("extractor_inner", C.c_double),
+                ("extractor_outer", C.c_double), ("capillary_voltage", C.c_double), ("extractor_voltage", C.c_double)]
+
+    def __init__(self):
+        super().__init__(3e-4, 1.326e-5, 1e-4, 1.4e-4, 0.0, -1350.0)
+
+
+def es_run(c, L, nu, cycles, params=None):
+    p = params or EsParams()
+    N = level_sizes(c, L)[-1]
+    norms, u, init = np.zeros(cycles), np.zeros(N ** 3), C.c_double(0)
+    lib().orc_es_run(c, L, nu, cycles, C.byref(p), P(norms), P(u), C.cast(C.byref(init), dp))
+    return norms, u, init.value
