@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     const int nout = a.i_hi - a.i_lo;
     const long long W = (long long)a.ntj * a.ntk * nout;
     int vb = blockIdx.x;
-    if (a.xcd_remap) {
+    if (a.xcd_remap == 1) {
         /* hardware deals blocks round-robin over the 8 XCDs (b % 8 names the XCD group, never which XCD); give
          * each group a contiguous run of shares.  Speed only. */
         const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = vb & 7, idx = vb >> 3;
@@ -164,7 +164,20 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     if (a.CI > 0) {
         /* lock-step mode: block -> (tile column, i-chunk), tile fastest: all tile columns of a chunk march through
          * the same planes at the same time, so a neighbour's halo rows are still in the Infinity Cache / L2 */
-        const int T = a.ntj * a.ntk, tl = vb % T, ch = vb / T;
+        const int T = a.ntj * a.ntk, ch = vb / T;
+        int tl = vb % T;
+        if (a.xcd_remap == 2) {
+            /* several rounds of blocks: inside every chunk's layer of T blocks, the blocks of one XCD group take a
+             * contiguous run of tile columns (renumbering the whole grid would scatter the first round over all
+             * chunks and break the lock-step).  Speed only. */
+            const int r0 = (ch * T) & 7, x = (r0 + tl) & 7;
+            int off = 0;
+            for (int y = 0; y < x; y++) {
+                const int first = (y - r0 + 8) & 7;
+                off += first < T ? (T - first + 7) >> 3 : 0;
+            }
+            tl = off + (tl - ((x - r0 + 8) & 7)) / 8;
+        }
         w0 = (long long)tl * nout + (long long)ch * a.CI;
         w1 = min(w0 + a.CI, (long long)(tl + 1) * nout);
     }
@@ -619,6 +632,20 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
         }
     }
     a.CI = (nout + best_nci - 1) / best_nci;
+    if (S >= 4 && RES == 0 && T < ncu && T * 8 > ncu) {
+        /* The four-pass launch is held back by the CUs a whole number of chunk layers leaves idle (513^3: 110 tile
+         * columns, two layers = 220 of 256 CUs) rather than by the memory system: m full layers of x planes and a
+         * short tail chunk that the left-over CUs work off in ceil(T / left) turns, sized so that both finish
+         * together (231 + 231 + 51 planes: 240 steps instead of 266; measured 0.751 against 0.779 ms).  The shorter
+         * pipelines do not gain from it (measured), they keep equal chunks. */
+        const int m = ncu / (int)T, left = ncu - m * (int)T;
+        if (left * 8 >= T) {
+            const int turns = ((int)T + left - 1) / left;
+            const int x = (turns * (nout + ovh) - ovh + m * turns) / (1 + m * turns);
+            if (x > 0 && nout - m * x > 0 && (double)(x + ovh) < 0.97 * best_cost)
+                a.CI = x;
+        }
+    }
     if (const char *e = getenv("MG3D_SWEEP_CI"))
         if (atoi(e) > 0)
             a.CI = atoi(e) < nout ? atoi(e) : nout;
@@ -626,9 +653,9 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
     a.snap = 0;
     /* one round: give each XCD group (blockIdx % 8) a contiguous run of tile columns -- neighbours then share an L2
      * (2 % at 513^3).  With several rounds the renumbering would scatter the first round over all chunks. */
-    a.xcd_remap = nb <= ncu && nb >= 64;
-    if (const char *e = getenv("MG3D_XCD"))
-        a.xcd_remap = atoi(e) == 1;
+    a.xcd_remap = nb < 64 ? 0 : nb <= ncu ? 1 : 2;
+    if (const char *e = getenv("MG3D_XCD")) /* 0 off, 1 whole grid (one round), 2 per chunk layer, 3: 1 or 2 by rounds */
+        a.xcd_remap = atoi(e) == 3 ? (nb < 64 ? 0 : nb <= ncu ? 1 : 2) : atoi(e);
     if (getenv("MG3D_SWEEP_BALANCED") && getenv("MG3D_SWEEP_BALANCED")[0] == '1') {
         /* experiment: equal shares of the linearised (tile column, plane) space, one block per CU, no lock-step */
         a.CI = 0;
