@@ -241,7 +241,11 @@ int mg3d32_restrict(mg3d32_ctx *ctx, int level);                   /* r(level) -
 int mg3d32_prolong(mg3d32_ctx *ctx, int level);                    /* u(level) += P u(level-1), mg_3d.h:1000-1145 */
 int mg3d32_coarse_solve(mg3d32_ctx *ctx);                          /* gauss_elim.h:31-60 through double */
 int mg3d32_vcycles(mg3d32_ctx *ctx, int count, double *norms);     /* mg_3d.h:1242-1362 with the Jacobi smoother */
-int mg3d32_fmg_initialize(mg3d32_ctx *ctx);                        /* F-cycle start, mg_dirichlet_analytic.c:771-806 */
+/* F-cycle start, mg_dirichlet_analytic.c:771-806.  Unlike the reference's vcycle (which zeroes u[q] on entry below the
+ * finest level, :698-700, and thereby discards the interpolated guess everywhere but on the finest level -- behaviour the
+ * fp64 mg3d_fmg_initialize reproduces), this variant zeroes only the coarser level before descending: the interpolated
+ * guess is kept on every level. */
+int mg3d32_fmg_initialize(mg3d32_ctx *ctx);
 
 /* The same variant on i-slabs of several GPUs (csrc/mg3d_f32_dist.hip; BASELINE configs[4]: 1025^3 on 8 GPUs): the
  * partition and schedule of mg3d_dist_* with H = smooth_iters + 2 halo planes (a Jacobi sweep uses up one plane per

@@ -152,3 +152,20 @@ def test_fused_and_separate_launches_agree(monkeypatch, knob):
             res.append((s.vcycles(4), s.download(MG3D_U, 4)))
     assert np.array_equal(res[0][1], res[1][1])
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-12)  # the fused norm sums in another order
+
+
+def test_fcycle_start_keeps_the_interpolated_guess():
+    """The reference's vcycle zeroes u[q] on entry below the finest level (mg_dirichlet_analytic.c:698-700), so its FMG
+    start (:771-806) keeps the interpolated guess only on the finest level; the fp64 path reproduces that (pinned).
+    This variant deliberately zeroes only the COARSER level before descending: the guess survives on every level and
+    the start already lands near the binary32 floor.  Pinned here: (a) residual right after the start, before any
+    V-cycle, orders of magnitude below the zero-guess residual; (b) the restatement does the same (bit parity above)."""
+    c, L, nu = 5, 5, 2
+    with M.Solver32(c, L, nu, OMEGA) as s:
+        s.setup_test_problem(fmg=False)
+        zero_guess = s.residual(L - 1, store=False)
+        s.setup_test_problem(fmg=True)
+        after_start = s.residual(L - 1, store=False)
+        floor = s.vcycles(6)[-1]
+    assert after_start < 1e-3 * zero_guess
+    assert after_start < 50 * floor  # the start itself is within a small factor of where V-cycles park
