@@ -537,3 +537,19 @@ def test_full_size_513_bit_exact_against_oracle():
     assert np.array_equal(u, want_u)
     np.testing.assert_allclose(got, want_norms, rtol=norm_rtol(513))
     O.lib().orc_set_threads(1)
+
+
+def test_unknown_sweep_shape_falls_back_to_the_default(monkeypatch):
+    """MG3D_SWEEP_CFG naming a shape that was not compiled must not refuse the launch (a refused launch used to leave the
+    buffers swapped and the norm at 0): the default shape runs, same bits."""
+    c, L, nu = 5, 4, 2
+    with M.Solver(c, L, nu) as s:
+        s.setup_test_problem()
+        want_n = s.vcycles(3)
+        want_u = s.download(MG3D_U, L - 1)
+    monkeypatch.setenv("MG3D_SWEEP_CFG", "9,9,9")
+    with M.Solver(c, L, nu) as s:
+        s.setup_test_problem()
+        got_n = s.vcycles(3)
+        assert np.array_equal(s.download(MG3D_U, L - 1), want_u)
+    assert np.array_equal(got_n, want_n) and got_n[-1] > 0
