@@ -157,15 +157,16 @@ def test_fused_and_separate_launches_agree(monkeypatch, knob):
 def test_fcycle_start_keeps_the_interpolated_guess():
     """The reference's vcycle zeroes u[q] on entry below the finest level (mg_dirichlet_analytic.c:698-700), so its FMG
     start (:771-806) keeps the interpolated guess only on the finest level; the fp64 path reproduces that (pinned).
-    This variant deliberately zeroes only the COARSER level before descending: the guess survives on every level and
-    the start already lands near the binary32 floor.  Pinned here: (a) residual right after the start, before any
-    V-cycle, orders of magnitude below the zero-guess residual; (b) the restatement does the same (bit parity above)."""
+    This variant deliberately zeroes only the COARSER level before descending: the guess survives on every level (at
+    1025^3 the first V-cycle behind the start already sits on the binary32 floor, tests/test_gpu_fullsize.py).  Pinned here: (a) the residual right after
+    the start, before any V-cycle, is orders of magnitude below the zero-guess residual; (b) the restatement does the
+    same (bit parity above)."""
     c, L, nu = 5, 5, 2
     with M.Solver32(c, L, nu, OMEGA) as s:
         s.setup_test_problem(fmg=False)
         zero_guess = s.residual(L - 1, store=False)
         s.setup_test_problem(fmg=True)
         after_start = s.residual(L - 1, store=False)
-        floor = s.vcycles(6)[-1]
-    assert after_start < 1e-3 * zero_guess
-    assert after_start < 50 * floor  # the start itself is within a small factor of where V-cycles park
+        n = s.vcycles(6)
+    assert after_start < 1e-3 * zero_guess  # 65^3: 88 against 3e5; a wiped guess would leave the zero-guess residual
+    assert n[0] < 0.2 * after_start and n[-1] < n[0]  # and the cycles carry on from there (65^3: 88 -> 9.4 -> ... -> 0.64)
