@@ -224,6 +224,30 @@ def f32_line(args):
     barrier()
     t_fmg = time.perf_counter() - t0
     after = s.vcycles(1)
+    slabs_ok = None
+    if (world > 1 or force_dist) and not args.no_verify:
+        # untimed self-check: the owned planes of every rank against a single-domain run of the same sequence on rank 0
+        import ctypes as C
+        import hashlib
+        import numpy as np
+        from multigrid_parallel_amd.binding import MG3D_U, lib as _lib
+        full = s.download(MG3D_U, L - 1)
+        lo, hi = C.c_int(0), C.c_int(0)
+        _lib().mg3d_slab_owned(c, L, world, s.halo, L - 1, rank, C.byref(lo), C.byref(hi))
+        mine = (lo.value, hi.value, hashlib.sha256(full.reshape(N, N * N)[lo.value:hi.value].tobytes()).hexdigest())
+        del full
+        parts = [mine]
+        if dist.is_initialized():
+            parts = [None] * world
+            dist.all_gather_object(parts, mine)
+        if rank == 0:
+            with M.Solver32(c, L, nu) as one:
+                one.setup_test_problem(fmg=True)
+                ref_after = one.vcycles(1)
+                ref = one.download(MG3D_U, L - 1).reshape(N, N * N)
+            slabs_ok = all(hashlib.sha256(ref[a:b].tobytes()).hexdigest() == h for a, b, h in parts) and \
+                bool(np.allclose(after, ref_after, rtol=1e-9, atol=0))
+            del ref
     if rank == 0:
         print(json.dumps({
             "metric": f"V-cycles/sec, {N}^3 Poisson, fp32, damped-Jacobi V({nu},{nu}) after an F-cycle start (parity unpinned)",
@@ -233,7 +257,7 @@ def f32_line(args):
             "config": {"workload": f"{N}^3 Poisson (args {c} {L} {nu}), Dirichlet x^2-2y^2+z^2, omega 6/7, device-resident",
                        "coarse_pts": c, "levels": L, "smooth_iters": nu, "parallelism": par},
             "fcycle_start_ms": t_fmg * 1e3, "first_norm": float(norms[0]), "last_norm": float(norms[-1]),
-            "norm_after_fcycle_start": float(after[0]),
+            "norm_after_fcycle_start": float(after[0]), "slabs_bit_identical_to_single_domain": slabs_ok,
             "roofline": {"bound": "hbm", "kernel": "whole V-cycle (compulsory bytes: every leg streams its fields once, w = 4)",
                          "achieved": comp / per / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": comp / per / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
@@ -253,6 +277,8 @@ def main():
     ap.add_argument("--levels", type=int, default=7)
     ap.add_argument("--smooth-iters", dest="nu", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="N > 1: skip the untimed comparison of the assembled slabs with a single-domain run")
     ap.add_argument("--cpu-cycles", type=int, default=8)
     ap.add_argument("--cpu-port", action="store_true", help="time oracle/ (port) even if oracle/_ref exists")
     ap.add_argument("--cpu-child", action="store_true", help=argparse.SUPPRESS)
@@ -319,6 +345,32 @@ def main():
                              device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        # Self-check of the slab decomposition, outside the timed region (--no-verify skips it): every rank hashes the
+        # planes it owns; rank 0 runs the same number of cycles on a single domain and hashes the same plane ranges.
+        # On a real multi-GPU run this is the first evidence that the RCCL exchanges move the right planes.
+        slabs_ok = None
+        if not args.no_verify:
+            import ctypes as C
+            import hashlib
+            import numpy as np
+            from multigrid_parallel_amd.binding import lib as _lib
+            full = solver.download(MG3D_U, L - 1)
+            lo, hi = C.c_int(0), C.c_int(0)
+            _lib().mg3d_slab_owned(c, L, world, solver.halo, L - 1, rank, C.byref(lo), C.byref(hi))
+            mine = (rank, lo.value, hi.value, hashlib.sha256(full.reshape(N, N * N)[lo.value:hi.value].tobytes()).hexdigest())
+            del full
+            parts = [mine]
+            if dist.is_initialized():
+                parts = [None] * world
+                dist.all_gather_object(parts, mine)
+            if rank == 0:
+                with M.Solver(c, L, nu) as one:
+                    one.setup_test_problem()
+                    ref_norms = one.vcycles(args.warmup + args.steps)
+                    ref = one.download(MG3D_U, L - 1).reshape(N, N * N)
+                slabs_ok = all(hashlib.sha256(ref[a:b].tobytes()).hexdigest() == h for _, a, b, h in parts) and \
+                    bool(np.allclose(list(warm_norms) + list(norms), ref_norms, rtol=1e-9, atol=0))
+                del ref
         rccl_ranks, overlap, dev = solver.comm_info()
         placement = [(rank, dev, torch.cuda.get_device_properties(dev).name)]
         if dist.is_initialized():
@@ -351,6 +403,7 @@ def main():
                 "rccl_ranks": rccl_ranks, "halo_overlap": overlap,
                 "ranks": [{"rank": r, "device": d, "name": n} for r, d, n in placement],
                 "history_matches_reference": known_ok,
+                "slabs_bit_identical_to_single_domain": slabs_ok,
                 # no per-kernel timers on the slab path: the whole cycle against the aggregate HBM peak (the
                 # per-kernel roofline and the CPU baseline belong to the N = 1 line)
                 "roofline": {"bound": "hbm", "kernel": "whole V-cycle, all ranks (compulsory bytes: every leg streams "

@@ -1,0 +1,31 @@
+#!/bin/bash
+# AddressSanitizer + UBSan over the CPU-side C code (GPU sanitizers are not available on the pool): the checker
+# (oracle/*.c: fp64, fp32 and mixed-boundary cycles) and the product's host side (csrc/mg3d_host.c: coarse operators,
+# LU factorisation, boundary fill, edge cosmetics).  Usage: tools/sanitize_cpu.sh   (no GPU needed)
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd); T=$(mktemp -d)
+SAN="-O1 -g -ffp-contract=off -fPIC -std=gnu99 -fsanitize=address,undefined -fno-omit-frame-pointer -shared"
+gcc $SAN -fopenmp -o $T/liboracle.so $R/oracle/mg3d_oracle.c $R/oracle/mg3d_oracle_f32.c $R/oracle/mg3d_oracle_es.c -lm 2>/dev/null
+gcc $SAN -I$R/include -I$R/multigrid_parallel_amd/csrc -o $T/libhost.so $R/multigrid_parallel_amd/csrc/mg3d_host.c -lm
+cat > $T/run.py <<PY
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, "$R/tests")
+import _oracle as O
+lib = C.CDLL("$T/liboracle.so"); real = C.CDLL; C.CDLL = lambda p: lib; O.lib(); C.CDLL = real
+print("fp64 V-cycles", O.run_problem(5, 4, 2, 4)[0])
+print("mixed-boundary", O.es_run(5, 3, 2, 4)[0])
+w, v = np.zeros(3), np.zeros(33 ** 3, dtype=np.float32)
+O.lib().orc32_run_problem(5, 4, 2, 6 / 7, 3, 1, O.P(w), O.PF(v)); print("fp32 F-cycle + V-cycles", w)
+H = C.CDLL("$T/libhost.so"); dp = C.POINTER(C.c_double)
+class P(C.Structure): _fields_ = [(n, C.c_double) for n in "abcdef"]
+p = P(3e-4, 1.326e-5, 1e-4, 1.4e-4, 0., -1350.)
+for N in (3, 5, 9):
+    n = N ** 3; A = np.zeros(n * n)
+    H.mg3d_es_coarse_matrix(A.ctypes.data_as(dp), N, C.c_double(3e-4 / (N - 1)), C.byref(p)); H.mg3d_lu_factor(A.ctypes.data_as(dp), n)
+    B = np.zeros(n * n); H.mg3d_coarse_matrix(B.ctypes.data_as(dp), N, C.c_double(.1)); H.mg3d_lu_factor(B.ctypes.data_as(dp), n)
+    v = np.zeros(n); H.mg3d_fill_boundary_host(v.ctypes.data_as(dp), N, C.c_double(1 / (N - 1))); H.mg3d_smooth_edges_host(v.ctypes.data_as(dp), N)
+    assert np.isfinite(A).all() and np.isfinite(B).all()
+print("host side ok")
+PY
+LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python3 $T/run.py
+rm -rf $T
