@@ -729,8 +729,23 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
         return fail(MG3D_ERR_STATE, "mg3d_vcycle: no coarse LU set (mg3d_ctx_build_coarse / mg3d_ctx_set_lu)");
     hipStream_t s = ctx->stream;
     const int L = ctx->L;
+    /* level 1 below the top of the cycle, small enough for one workgroup's LDS: two launches instead of five */
+    const bool no_tiny = getenv("MG3D_NO_TINY") && getenv("MG3D_NO_TINY")[0] == '1'; /* read per cycle: tests toggle it */
+    const bool tiny = !no_tiny && ctx->fused && !ctx->keep_r && q >= 2 && ctx->iters >= 1 && k_tiny_fits(ctx->lv[1].g, ctx->lv[0].g);
     for (int l = q; l >= 1; l--) {
         Level &lev = ctx->lv[l];
+        if (l == 1 && tiny) {
+            {
+                StageScope t(ctx, l, MG3D_ST_SMOOTH1);
+                StageScope kt(ctx, l, MG3D_K_SWEEP4, true);
+                k_tiny_down(lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.f[MG3D_R], ctx->lv[0].g, ctx->lv[0].f[MG3D_D], lev.h,
+                            ctx->iters, s); /* :1258 + :1282 + :1294 + :1310 */
+            }
+            { StageScope t(ctx, l, MG3D_ST_RESIDUAL1); } /* inside the launch above: counted, ~0 s */
+            { StageScope t(ctx, l, MG3D_ST_RESTRICT); }
+            ctx->faces_dirty[l] = 0; /* the launch injects the faces itself */
+            continue;
+        }
         /* :1258-1259: the zero initial guess of a coarser level; with the fused sweep the first launch simply
          * does not read u (and writes every plane of the other buffer), so no memset is needed */
         const bool zero_in = l < L - 1 && ctx->fused && ctx->iters > 0;
@@ -774,6 +789,17 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
     }
     for (int l = 1; l <= q; l++) {
         Level &lev = ctx->lv[l];
+        if (l == 1 && tiny) {
+            { StageScope t(ctx, l, MG3D_ST_PROLONG); } /* inside the launch below */
+            {
+                StageScope t(ctx, l, MG3D_ST_SMOOTH2);
+                StageScope kt(ctx, l, MG3D_K_SWEEP4, true);
+                k_tiny_up(lev.g, lev.f[MG3D_U], lev.f[MG3D_D], ctx->lv[0].g, ctx->lv[0].f[MG3D_U], lev.h, ctx->iters,
+                          s); /* :1331 + :1341 */
+            }
+            { StageScope t(ctx, l, MG3D_ST_RESIDUAL2); }
+            continue;
+        }
         const int want_norm = l == q ? 1 : 0;
         const bool pro = pro_fusable(ctx, ctx->iters, want_norm);
         {

@@ -74,6 +74,13 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
             trilinear prolongation of the coarse field ec (smoothing-only launches, S = 2 or 4) */,
             int i_lo = -1, int i_hi = -1 /* local output planes of this launch; default all.  Several launches
             with disjoint windows and the same vin/vout make up one sweep (overlap with halo exchange) */);
+/* mg3d_tiny.hip: the level above the coarsest one in one workgroup (LDS-resident), when it fits (N <= 17) */
+bool k_tiny_fits(const Geom &g, const Geom &gc);
+/* zero guess, `iters` x (red, black), residual, restriction (interior + face injection from r's boundary) into dc */
+void k_tiny_down(const Geom &g, double *u, const double *d, const double *r, const Geom &gc, double *dc, double h, int iters,
+                 hipStream_t s);
+/* u += P(ec) at every point, then `iters` x (black, red) */
+void k_tiny_up(const Geom &g, double *u, const double *d, const Geom &gc, const double *ec, double h, int iters, hipStream_t s);
 /* b and x are level-0 grids in the padded layout g0; work holds 2n doubles */
 /* steps per chunk of the streamed solve for n unknowns and rot_r = R on the current device, 0 if it cannot run */
 int mg3d_lu_stream_chunk(int n, int R);

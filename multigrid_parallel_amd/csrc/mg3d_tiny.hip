@@ -1,0 +1,212 @@
+/*
+ * mg3d_tiny.hip -- the level above the coarsest one (17^3 for the usual 9^3 coarse grid) in ONE workgroup.
+ *
+ * A visit of that level by the V-cycle (mg_3d.h:1242-1362) is eight dependent colour passes, a residual, a restriction
+ * and a prolongation on 4913 points: as launches of the plane-marching sweep it costs five launches of 8-20 us each
+ * (pipeline fill and drain, not work).  The whole level fits the LDS of one CU three times over (u, d, r: 39 KB each),
+ * so two launches do it: `tiny_down` (zero guess, pre-smoothing, residual, full-weighting restriction into the coarsest
+ * right-hand side) in front of the direct solve and `tiny_up` (prolongation, post-smoothing) behind it, every colour
+ * pass one LDS sweep and one workgroup barrier.  Every expression is the one of the reference with its association
+ * (update mg_3d.h:438-443, residual :819-821, restriction :961-995 with the ti, tj, tk order, face injection :879-958,
+ * prolongation :1000-1145 with the parent order per parity class), no contraction: bit-identical to the generic
+ * kernels (tests/test_gpu_parity.py compares both paths).
+ */
+#include "mg3d_internal.h"
+
+#define TINY_MAX_N 17
+#define TINY_THREADS 1024
+
+__device__ __forceinline__ int lidx(int N, int i, int j, int k) { return (i * N + j) * N + k; }
+
+/* one colour pass over the LDS copy (mg_3d.h:438-443, 658-702) */
+__device__ __forceinline__ void tiny_pass(double *u, const double *d, int N, double hSq, double sixth, int color)
+{
+    const int M = N - 2, n = M * M * M;
+    for (int t = threadIdx.x; t < n; t += TINY_THREADS) {
+        const int i = 1 + t / (M * M), j = 1 + (t / M) % M, k = 1 + t % M;
+        if (((i + j + k) & 1) != color)
+            continue;
+        const int p = lidx(N, i, j, k);
+        double s = u[p - N * N] + u[p + N * N];
+        s = s + u[p - N];
+        s = s + u[p + N];
+        s = s + u[p - 1];
+        s = s + u[p + 1];
+        s = s - hSq * d[p];
+        u[p] = sixth * s;
+    }
+    __syncthreads();
+}
+
+/* zero guess (mg_3d.h:1258-1259), `iters` x (red, black) (:1282), residual (:1294), restriction into dc (:1310) */
+__global__ void __launch_bounds__(TINY_THREADS) tiny_down_kernel(Geom g, double *__restrict__ u_out,
+                                                                const double *__restrict__ d_in,
+                                                                const double *__restrict__ r_in, Geom gc,
+                                                                double *__restrict__ dc, double hSq, double sixth,
+                                                                double invHsq, int iters)
+{
+    extern __shared__ double lds[];
+    const int N = g.N, n = N * N * N, Nc = gc.N;
+    double *u = lds, *d = lds + n, *r = lds + 2 * n;
+    for (int t = threadIdx.x; t < n; t += TINY_THREADS) {
+        const int i = t / (N * N), j = (t / N) % N, k = t % N;
+        u[t] = 0.;
+        d[t] = d_in[g.plane * i + (long long)g.pitch * j + k];
+    }
+    __syncthreads();
+    for (int s = 0; s < iters; s++) {
+        tiny_pass(u, d, N, hSq, sixth, 1);
+        tiny_pass(u, d, N, hSq, sixth, 0);
+    }
+    /* residual on the interior (mg_3d.h:819-821); the boundary entries of r are whatever the level's r array holds
+     * (nothing ever writes them, :824-825) -- only the face injection below reads them, straight from memory */
+    {
+        const int M = N - 2, m = M * M * M;
+        for (int t = threadIdx.x; t < m; t += TINY_THREADS) {
+            const int i = 1 + t / (M * M), j = 1 + (t / M) % M, k = 1 + t % M;
+            const int p = lidx(N, i, j, k);
+            double s = u[p - N * N] + u[p + N * N];
+            s = s + u[p - N];
+            s = s + u[p + N];
+            s = s + u[p - 1];
+            s = s + u[p + 1];
+            s = s - 6 * u[p];
+            r[p] = d[p] - invHsq * s;
+        }
+    }
+    __syncthreads();
+    /* restriction (mg_3d.h:844-998): 27-point sum in ti, tj, tk order from 0 on the interior, injection on the faces */
+    for (int t = threadIdx.x; t < Nc * Nc * Nc; t += TINY_THREADS) {
+        const int ic = t / (Nc * Nc), jc = (t / Nc) % Nc, kc = t % Nc;
+        const bool face = ic == 0 || ic == Nc - 1 || jc == 0 || jc == Nc - 1 || kc == 0 || kc == Nc - 1;
+        double val;
+        if (face) {
+            val = r_in[g.plane * (2 * ic) + (long long)g.pitch * (2 * jc) + 2 * kc];
+        } else {
+            val = 0.;
+            const int pf = lidx(N, 2 * ic, 2 * jc, 2 * kc);
+#pragma unroll
+            for (int ti = -1; ti <= 1; ti++)
+#pragma unroll
+                for (int tj = -1; tj <= 1; tj++)
+#pragma unroll
+                    for (int tk = -1; tk <= 1; tk++) {
+                        const double w = (ti ? 0.25 : 0.5) * (tj ? 0.25 : 0.5) * (tk ? 0.25 : 0.5);
+                        val += r[pf + ti * N * N + tj * N + tk] * w;
+                    }
+        }
+        dc[gc.plane * ic + (long long)gc.pitch * jc + kc] = val;
+    }
+    for (int t = threadIdx.x; t < n; t += TINY_THREADS) {
+        const int i = t / (N * N), j = (t / N) % N, k = t % N;
+        u_out[g.plane * i + (long long)g.pitch * j + k] = u[t];
+    }
+}
+
+/* prolongation + correction at every fine point (mg_3d.h:1331 -> :1000-1145), `iters` x (black, red) (:1341) */
+__global__ void __launch_bounds__(TINY_THREADS) tiny_up_kernel(Geom g, double *__restrict__ u_io,
+                                                              const double *__restrict__ d_in, Geom gc,
+                                                              const double *__restrict__ ec_in, double hSq, double sixth,
+                                                              int iters)
+{
+    extern __shared__ double lds[];
+    const int N = g.N, n = N * N * N, Nc = gc.N, nc = Nc * Nc * Nc;
+    double *u = lds, *d = lds + n, *ec = lds + 2 * n;
+    for (int t = threadIdx.x; t < n; t += TINY_THREADS) {
+        const int i = t / (N * N), j = (t / N) % N, k = t % N;
+        const long long q = g.plane * i + (long long)g.pitch * j + k;
+        u[t] = u_io[q];
+        d[t] = d_in[q];
+    }
+    for (int t = threadIdx.x; t < nc; t += TINY_THREADS) {
+        const int i = t / (Nc * Nc), j = (t / Nc) % Nc, k = t % Nc;
+        ec[t] = ec_in[gc.plane * i + (long long)gc.pitch * j + k];
+    }
+    __syncthreads();
+    const int sI = Nc * Nc, sJ = Nc, sK = 1;
+    for (int t = threadIdx.x; t < n; t += TINY_THREADS) {
+        const int i = t / (N * N), j = (t / N) % N, k = t % N;
+        const int oi = i & 1, oj = j & 1, ok = k & 1;
+        const int c0 = (((i - oi) / 2) * Nc + (j - oj) / 2) * Nc + (k - ok) / 2;
+        double x = 0.;
+        switch (oi + oj + ok) {
+        case 3:
+            x += ec[c0];
+            x += ec[c0 + sK];
+            x += ec[c0 + sJ];
+            x += ec[c0 + sJ + sK];
+            x += ec[c0 + sI];
+            x += ec[c0 + sI + sK];
+            x += ec[c0 + sI + sJ];
+            x += ec[c0 + sI + sJ + sK];
+            x *= 0.125;
+            break;
+        case 2:
+            if (!oi) {
+                x += ec[c0];
+                x += ec[c0 + sJ];
+                x += ec[c0 + sK];
+                x += ec[c0 + sJ + sK];
+            } else if (!oj) {
+                x += ec[c0];
+                x += ec[c0 + sI];
+                x += ec[c0 + sK];
+                x += ec[c0 + sI + sK];
+            } else {
+                x += ec[c0];
+                x += ec[c0 + sJ];
+                x += ec[c0 + sI];
+                x += ec[c0 + sI + sJ];
+            }
+            x *= 0.25;
+            break;
+        case 1:
+            x += ec[c0];
+            x += ec[c0 + oi * sI + oj * sJ + ok * sK];
+            x *= 0.5;
+            break;
+        default:
+            x = ec[c0];
+        }
+        u[t] += x;
+    }
+    __syncthreads();
+    for (int s = 0; s < iters; s++) {
+        tiny_pass(u, d, N, hSq, sixth, 0);
+        tiny_pass(u, d, N, hSq, sixth, 1);
+    }
+    for (int t = threadIdx.x; t < n; t += TINY_THREADS) {
+        const int i = t / (N * N), j = (t / N) % N, k = t % N;
+        u_io[g.plane * i + (long long)g.pitch * j + k] = u[t];
+    }
+}
+
+bool k_tiny_fits(const Geom &g, const Geom &gc)
+{
+    return g.ig0 == 0 && g.ni == g.N && g.nj == g.N && g.nk == g.N && g.N >= 3 && g.N <= TINY_MAX_N && gc.N == (g.N + 1) / 2 &&
+           gc.ig0 == 0 && gc.ni == gc.N;
+}
+
+void k_tiny_down(const Geom &g, double *u, const double *d, const double *r, const Geom &gc, double *dc, double h, int iters,
+                 hipStream_t s)
+{
+    const size_t lds = sizeof(double) * 3 * (size_t)g.N * g.N * g.N;
+    static bool attr = false;
+    if (!attr) { /* 118 KB of dynamic LDS at 17^3: above the 64 KB a kernel gets without asking */
+        (void)hipFuncSetAttribute((const void *)tiny_down_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(tiny_down_kernel, dim3(1), dim3(TINY_THREADS), lds, s, g, u, d, r, gc, dc, h * h, 1. / 6, 1. / (h * h),
+                       iters);
+}
+
+void k_tiny_up(const Geom &g, double *u, const double *d, const Geom &gc, const double *ec, double h, int iters, hipStream_t s)
+{
+    const size_t lds = sizeof(double) * (2 * (size_t)g.N * g.N * g.N + (size_t)gc.N * gc.N * gc.N);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)tiny_up_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(tiny_up_kernel, dim3(1), dim3(TINY_THREADS), lds, s, g, u, d, gc, ec, h * h, 1. / 6, iters);
+}

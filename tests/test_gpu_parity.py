@@ -553,3 +553,22 @@ def test_unknown_sweep_shape_falls_back_to_the_default(monkeypatch):
         got_n = s.vcycles(3)
         assert np.array_equal(s.download(MG3D_U, L - 1), want_u)
     assert np.array_equal(got_n, want_n) and got_n[-1] > 0
+
+
+@pytest.mark.parametrize("c,L,nu", [(9, 4, 2), (5, 5, 2), (3, 6, 3), (9, 3, 1)])
+def test_single_workgroup_level_equals_the_generic_kernels(monkeypatch, c, L, nu):
+    """The level above the coarsest one runs LDS-resident in one workgroup (csrc/mg3d_tiny.hip: two launches instead of
+    five); MG3D_NO_TINY=1 keeps the plane-marching kernels.  Same bits on every level, and both equal the oracle."""
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MG3D_NO_TINY", flag)
+        with M.Solver(c, L, nu) as s:
+            s.setup_test_problem()
+            norms = s.vcycles(4)
+            res.append((norms, [s.download(MG3D_U, l) for l in range(L)], [s.download(MG3D_D, l) for l in range(L - 1)]))
+    assert np.array_equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert np.array_equal(a, b)
+    want_norms, want_u, _, _ = O.run_problem(c, L, nu, 4)
+    assert np.array_equal(res[0][1][-1], want_u)
+    np.testing.assert_allclose(res[0][0], want_norms, rtol=norm_rtol((c - 1) * (1 << (L - 1)) + 1))
