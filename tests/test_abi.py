@@ -158,3 +158,16 @@ def test_fp32_slab_partition_is_the_fp64_one_with_its_own_halo():
             if prev is not None:
                 assert [lo for lo, _ in cuts] == [2 * lo for lo, _ in prev]
             prev = cuts
+
+
+def test_bench_self_launch_explains_missing_gpus():
+    """`python bench.py --gpus N` without a launcher becomes the launcher (torch.distributed.run as a child process);
+    with fewer than N visible GPUs it must say so and exit 2 -- not a Python usage error, not a hang."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2
+    assert "needs 64 visible GPUs" in r.stderr and "one rank per GPU" in r.stderr
+    assert r.stdout.strip() == ""

@@ -85,3 +85,25 @@ def test_vcycle_random_rhs(c, L, nu, seed, keep):
         for l in range(L - 1):
             assert np.array_equal(s.download(1, l), H.d[l])
     np.testing.assert_allclose(got, want, rtol=1e-11)
+
+
+@pytest.mark.parametrize("N,iters,post", [(66, 2, False), (131, 2, True), (200, 1, False), (258, 2, True), (301, 2, False),
+                                          (301, 3, True)])
+def test_ragged_multi_tile_sizes(N, iters, post):
+    """Sizes that are neither 2^k+1 nor a single tile: several j- and k-tiles with ragged last tiles, several i-chunks
+    (equal, with a short tail, one or many rounds of blocks), both k-tilings, the XCD grouping of tile columns.  Smoother
+    passes (4-pass and 2-pass launches) and the stored residual, bit for bit; the norm to the summation order."""
+    h = 1.0 / (N - 1)
+    v, d = field(N ** 3, 1000 + N, 1.0), field(N ** 3, 2000 + N, 1e2)
+    want, got = v.copy(), v.copy()
+    O.lib().orc_set_threads(O.lib().orc_max_threads())
+    (O.lib().orc_post_smooth if post else O.lib().orc_pre_smooth)(O.P(want), O.P(d), N, h, iters)
+    check(M.lib().mg3d_host_smooth(P(got), P(d), N, h, iters, int(post)))
+    assert np.array_equal(got, want)
+    rw, rg = np.zeros(N ** 3), np.zeros(N ** 3)
+    wn = O.lib().orc_residual(O.P(want), O.P(d), N, h, O.P(rw))
+    gn = C.c_double(0)
+    check(M.lib().mg3d_host_residual(P(got), P(d), N, h, P(rg), C.byref(gn)))
+    assert np.array_equal(rg, rw)
+    assert gn.value == pytest.approx(wn, rel=max(1e-11, 0.5 * (N - 2) ** 3 * 2.0 ** -53))
+    O.lib().orc_set_threads(1)
