@@ -19,3 +19,17 @@ for P in [int(x) for x in (sys.argv[1:] or ["2", "4", "8"])]:
         t0 = time.perf_counter(); n = d.vcycles(steps); t1 = time.perf_counter()
     ok = np.allclose(n, ref, rtol=1e-10)
     print(f"loopback {P} ranks      : {(t1 - t0) / steps * 1e3:7.3f} ms/cycle  first distributed level {d.first_level}, halo {d.halo}, norms match: {ok}")
+
+# ---- the fp32 / Jacobi variant (BASELINE configs[4]): 1025^3 on P virtual ranks (MG3D_LOOPBACK_F32=0 skips it)
+if os.environ.get("MG3D_LOOPBACK_F32", "1") == "1":
+    c, L, nu = 9, 8, 2
+    with M.Solver32(c, L, nu) as s:
+        s.setup_test_problem(fmg=False); s.vcycles(2); s.sync()
+        t0 = time.perf_counter(); ref = s.vcycles(steps); t1 = time.perf_counter()
+    print(f"fp32 1025^3 single domain : {(t1 - t0) / steps * 1e3:7.3f} ms/cycle")
+    for P in [int(x) for x in (sys.argv[1:] or ["2", "4", "8"])]:
+        with M.DistSolver32(c, L, nu, nranks=P) as d:
+            d.setup_test_problem(fmg=False); d.vcycles(2); d.sync()
+            t0 = time.perf_counter(); n = d.vcycles(steps); t1 = time.perf_counter()
+        print(f"fp32 loopback {P} ranks    : {(t1 - t0) / steps * 1e3:7.3f} ms/cycle  first distributed level {d.first_level}, "
+              f"halo {d.halo}, norms match: {np.allclose(n, ref, rtol=1e-10)}")
