@@ -651,8 +651,10 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
             a.CI = atoi(e) < nout ? atoi(e) : nout;
     long long nb = T * ((nout + a.CI - 1) / a.CI);
     a.snap = 0;
-    /* one round: give each XCD group (blockIdx % 8) a contiguous run of tile columns -- neighbours then share an L2
-     * (2 % at 513^3).  With several rounds the renumbering would scatter the first round over all chunks. */
+    /* XCD grouping: the blocks of one XCD group (blockIdx % 8) take a contiguous run of tile columns, so that
+     * neighbouring tile columns mostly share an L2 (a tenth to a quarter fewer bytes from the fabric).  One round of
+     * blocks: renumber the whole grid (1); several rounds: inside every chunk's layer (2) -- renumbering the whole
+     * grid would scatter the first round over all chunks and break the lock-step. */
     a.xcd_remap = nb < 64 ? 0 : nb <= ncu ? 1 : 2;
     if (const char *e = getenv("MG3D_XCD")) /* 0 off, 1 whole grid (one round), 2 per chunk layer, 3: 1 or 2 by rounds */
         a.xcd_remap = atoi(e) == 3 ? (nb < 64 ? 0 : nb <= ncu ? 1 : 2) : atoi(e);
