@@ -114,6 +114,38 @@ __device__ __forceinline__ double lane_from_right(double x) /* lane l receives l
 #endif
 }
 
+/* Cache policy of the streams (compile-time MG3D_NT bits: 1 = u loads, 4 = d loads, 2 = u stores non-temporal, 8 = in
+ * the pure residual launches (S = 0) the loads of the rows no other tile column reads; default 2 + 8).
+ * The output is not read again before the next launch, a gigabyte later: written non-temporally it does not push the
+ * halo rows the neighbouring tile columns are about to re-read out of L2 / the Infinity Cache (513^3: 265 -> 274
+ * V-cycles/s).  Non-temporal LOADS lose exactly those halo re-reads (231 V-cycles/s); write-through stores
+ * (`sc1`, `sc0 sc1`, `sc1 nt` by inline asm) measured 258-263.  Loading only the read-once rows non-temporally
+ * helps the residual + restriction launch (0.64 -> 0.59 ms) and hurts the smoothing launches (0.72 -> 0.88). */
+typedef double v2d __attribute__((ext_vector_type(2)));
+#ifndef MG3D_NT
+#define MG3D_NT 10
+#endif
+template <int BIT> __device__ __forceinline__ double2 ld_stream(const double *p)
+{
+    if constexpr ((MG3D_NT & BIT) != 0) {
+        const v2d x = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+        return make_double2(x.x, x.y);
+    } else {
+        return *reinterpret_cast<const double2 *>(p);
+    }
+}
+__device__ __forceinline__ void st_stream(double *p, double2 o)
+{
+#if (MG3D_NT & 2)
+    v2d x;
+    x.x = o.x;
+    x.y = o.y;
+    __builtin_nontemporal_store(x, reinterpret_cast<v2d *>(p));
+#else
+    *reinterpret_cast<double2 *>(p) = o;
+#endif
+}
+
 template <int S, int RES, int RJ, int NW, int PF, bool PRO>
 __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 {
@@ -202,7 +234,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     const int nsteps = (i_out1 - 1 + ST) - i_s + 1 + (RES == 2 ? 2 : 0);
 
     /* per-row / per-column masks */
-    bool row_in[RJ], row_upd[RJ], row_own[RJ];
+    bool row_in[RJ], row_upd[RJ], row_own[RJ], row_once[RJ];
     long long row_off[RJ];
 #pragma unroll
     for (int rr = 0; rr < RJ; rr++) {
@@ -210,6 +242,8 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         row_in[rr] = j >= 0 && j < g.nj;
         row_upd[rr] = j >= 1 && j <= g.nj - 2;
         row_own[rr] = row_in[rr] && j >= tj * VJ && j < (tj + 1) * VJ;
+        /* rows no other tile column reads (the outer HJ owned rows are the neighbours' halo) */
+        row_once[rr] = row_in[rr] && j >= tj * VJ + HJ && j < (tj + 1) * VJ - HJ;
         row_off[rr] = (long long)g.pitch * j + kA;
     }
     const bool col_in[2] = {kA >= 0 && kA < g.nk, kA + 1 >= 0 && kA + 1 < g.nk};
@@ -254,8 +288,16 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                 const long long p = g.plane * i + row_off[rr];
                 /* vin == NULL: the input field is identically zero (a coarse level's initial guess,
                  * mg_3d.h:1258-1259) -- neither zeroed in memory beforehand nor read */
-                vv[rr] = a.vin ? *reinterpret_cast<const double2 *>(a.vin + p) : make_double2(0., 0.);
-                dd[rr] = *reinterpret_cast<const double2 *>(a.d + p);
+#if (MG3D_NT & 8)
+                if (S == 0 && row_once[rr]) { /* wave-uniform */
+                    vv[rr] = a.vin ? ld_stream<8>(a.vin + p) : make_double2(0., 0.);
+                    dd[rr] = ld_stream<8>(a.d + p);
+                } else
+#endif
+                {
+                    vv[rr] = a.vin ? ld_stream<1>(a.vin + p) : make_double2(0., 0.);
+                    dd[rr] = ld_stream<4>(a.d + p);
+                }
             } else {
                 vv[rr] = make_double2(0., 0.);
                 dd[rr] = make_double2(0., 0.);
@@ -443,7 +485,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                     o.x = X ? other : nw[S];
                     o.y = X ? nw[S] : other;
                     if (pair_own)
-                        *reinterpret_cast<double2 *>(a.vout + g.plane * q + row_off[rr]) = o;
+                        st_stream(a.vout + g.plane * q + row_off[rr], o);
                 }
             }
             if constexpr (RES != 0) {
