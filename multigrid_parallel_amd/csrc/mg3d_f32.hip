@@ -906,6 +906,8 @@ bool e32_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot, bool prolo
             const bool with_pro = prolong_first && !no_fuse && it == 0;
             const int py = (l.g.nj + (with_norm ? J2N_OUT_ROWS : J2_OUT_ROWS) - 1) / (with_norm ? J2N_OUT_ROWS : J2_OUT_ROWS);
             int ch = 128;
+            if (const char *e = getenv("MG3D_F32_CH")) /* tuning knob: planes per i-chunk of the paired sweep */
+                ch = atoi(e) > 0 ? atoi(e) : ch;
             while (ch > 8 && (long long)px * py * ((l.g.ni + ch - 1) / ch) < 1024)
                 ch /= 2;
             while (with_norm && (long long)px * py * ((l.g.ni + ch - 1) / ch) > MG3D_MAX_PARTIALS)
@@ -985,6 +987,8 @@ void e32_residual_restrict(mg3d32_ctx *ctx, int level, int c_lo, int c_hi)
     if (i_hi > i_lo) {
         const int nc = i_hi - i_lo;
         int cch = 64; /* coarse planes per block */
+        if (const char *e = getenv("MG3D_F32_CCH"))
+            cch = atoi(e) > 0 ? atoi(e) : cch;
         while (cch > 4 && (long long)px * py * ((nc + cch - 1) / cch) < 1024)
             cch /= 2;
         hipLaunchKernelGGL(residual_restrict32_kernel, dim3(px, py, (nc + cch - 1) / cch), dim3(64, J2_ROWS, 1), 0,
