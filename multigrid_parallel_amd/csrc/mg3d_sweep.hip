@@ -32,11 +32,13 @@
  * points on every side that is recomputed redundantly.  Output goes to a second array (the halo makes an
  * in-place update racy between tiles).
  *
- * Work distribution: the launch is PERSISTENT -- one block per CU slot, and the (tile column, plane) space,
- * linearised tile-major, is cut into gridDim.x equal shares.  A block marches through its share as one or two
- * segments (the tail of one tile column, the head of the next), each with H warm-up planes: every CU gets the
- * same number of steps, there is no partially filled last round of blocks, and a 513^3 level pays warm-up on
- * ~1.4 segments of ~220 planes per block instead of one per 64..128-plane chunk.
+ * Work distribution: lock-step chunks -- block -> (tile column, i-chunk), tile fastest, so all tile columns of a chunk
+ * march through the same planes at the same time and find their neighbours' halo rows in L2 / the Infinity Cache
+ * (launch_sweep picks the chunk length).  MG3D_SWEEP_BALANCED=1 keeps the experiment it replaced: one block per CU and
+ * equal shares of the linearised (tile column, plane) space, 1.3-1.5x slower for want of that sharing.
+ * Scalar unit: every per-row / per-plane test is wave-uniform (the wave index goes through readfirstlane); they are
+ * joined with `&` and selects rather than short-circuits wherever the register budget allows, because a branch per
+ * row and stage (78 a step) cost the four-pass launch 9 % at 513^3 and 20 % on the levels below 129^3.
  * k-tiling: tiles start at multiples of 112 columns (128-byte aligned rows of 16 doubles) whenever that needs
  * no more tiles than the tightest packing, so a tile row is exactly eight cache lines.
  */
@@ -168,14 +170,17 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     /* the wave index through readfirstlane: the compiler then knows that everything derived from it (the row
      * flags below) is wave-uniform and keeps it in scalar registers and scalar branches instead of 64-bit lane
      * masks -- the residual variants of this kernel were bound by the CU's one scalar ALU, not by memory */
-#ifdef MG3D_NO_UNIFORM_W
-    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-#else
-    const int lane = threadIdx.x & (WAVE - 1), w = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+#ifndef MG3D_UNIFORM_W
+#define MG3D_UNIFORM_W 2 /* 0: never, 1: residual variants only, 2: every variant */
 #endif
-    /* this block's share [w0, w1) of the linearised (tile column, output plane) space */
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int w = (MG3D_UNIFORM_W == 2 || (MG3D_UNIFORM_W == 1 && RES != 0)) ? __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE)
+                                                                             : (int)(threadIdx.x / WAVE);
+    /* this block's work: in lock-step mode one segment (tile column t_lin, planes off .. off+len of the output range);
+     * in the balanced experiment its share [w0, w1) of the linearised (tile column, output plane) space, one or two
+     * segments.  The 64-bit divisions of the latter are ~1400 instructions of prologue (5-6 us per launch, a quarter
+     * of a whole launch on the levels below 129^3): they stay behind the mode test. */
     const int nout = a.i_hi - a.i_lo;
-    const long long W = (long long)a.ntj * a.ntk * nout;
     int vb = blockIdx.x;
     if (a.xcd_remap == 1) {
         /* hardware deals blocks round-robin over the 8 XCDs (b % 8 names the XCD group, never which XCD); give
@@ -183,42 +188,57 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = vb & 7, idx = vb >> 3;
         vb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
     }
-    auto cut = [&](int k) -> long long {
-        long long x = W * k / gridDim.x;
-        const int r = (int)(x % nout);
-        if (r < a.snap)
-            x -= r;
-        else if (nout - r < a.snap)
-            x += nout - r;
-        return x;
-    };
-    long long w0 = cut(vb), w1 = cut(vb + 1);
-    if (a.CI > 0) {
-        /* lock-step mode: block -> (tile column, i-chunk), tile fastest: all tile columns of a chunk march through
-         * the same planes at the same time, so a neighbour's halo rows are still in the Infinity Cache / L2 */
+    long long w0 = 0, w1 = 0;
+    int t_lin = 0, off = 0, len = 0;
+    const bool lockstep = a.CI > 0;
+    if (lockstep) {
+        /* block -> (tile column, i-chunk), tile fastest: all tile columns of a chunk march through the same planes at
+         * the same time, so a neighbour's halo rows are still in the Infinity Cache / L2 */
         const int T = a.ntj * a.ntk, ch = vb / T;
-        int tl = vb % T;
+        int tl = vb - ch * T;
         if (a.xcd_remap == 2) {
             /* several rounds of blocks: inside every chunk's layer of T blocks, the blocks of one XCD group take a
              * contiguous run of tile columns (renumbering the whole grid would scatter the first round over all
              * chunks and break the lock-step).  Speed only. */
             const int r0 = (ch * T) & 7, x = (r0 + tl) & 7;
-            int off = 0;
+            int o = 0;
             for (int y = 0; y < x; y++) {
                 const int first = (y - r0 + 8) & 7;
-                off += first < T ? (T - first + 7) >> 3 : 0;
+                o += first < T ? (T - first + 7) >> 3 : 0;
             }
-            tl = off + (tl - ((x - r0 + 8) & 7)) / 8;
+            tl = o + (tl - ((x - r0 + 8) & 7)) / 8;
         }
-        w0 = (long long)tl * nout + (long long)ch * a.CI;
-        w1 = min(w0 + a.CI, (long long)(tl + 1) * nout);
+        t_lin = tl;
+        off = ch * a.CI;
+        len = min(a.CI, nout - off);
+    } else {
+        const long long W = (long long)a.ntj * a.ntk * nout;
+        auto cut = [&](int k) -> long long {
+            long long x = W * k / gridDim.x;
+            const int r = (int)(x % nout);
+            if (r < a.snap)
+                x -= r;
+            else if (nout - r < a.snap)
+                x += nout - r;
+            return x;
+        };
+        w0 = cut(vb);
+        w1 = cut(vb + 1);
     }
     double acc = 0.;
 
-    for (; w0 < w1;) {
-    const int t_lin = (int)(w0 / nout), off = (int)(w0 - (long long)t_lin * nout);
-    const int len = (int)min((long long)(nout - off), w1 - w0);
-    w0 += len;
+    for (bool more = true; more;) {
+    if (lockstep) {
+        more = false;
+    } else {
+        if (w0 >= w1)
+            break;
+        t_lin = (int)(w0 / nout);
+        off = (int)(w0 - (long long)t_lin * nout);
+        len = (int)min((long long)(nout - off), w1 - w0);
+        w0 += len;
+        more = w0 < w1;
+    }
     const int tk = t_lin % a.ntk, tj = t_lin / a.ntk;
 
     const int jt0 = tj * VJ - HJ, kt0 = tk * a.vk;
@@ -282,10 +302,12 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 
     auto load_plane = [&](int i, double2(&vv)[RJ], double2(&dd)[RJ]) {
         const bool pl = i >= 0 && i < g.ni;
+        long long pbase = g.plane * i;
+        asm volatile("" : "+s"(pbase)); /* one scalar 64-bit product per plane, not one re-materialised per row */
 #pragma unroll
         for (int rr = 0; rr < RJ; rr++) {
             if (pl && row_in[rr] && pair_load) {
-                const long long p = g.plane * i + row_off[rr];
+                const long long p = pbase + row_off[rr];
                 /* vin == NULL: the input field is identically zero (a coarse level's initial guess,
                  * mg_3d.h:1258-1259) -- neither zeroed in memory beforehand nor read */
 #if (MG3D_NT & 8)
@@ -418,17 +440,39 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         double e_top[STX], e_bot[STX];
 #pragma unroll
         for (int s = 0; s < STX; s++) {
-            e_top[s] = (w > 0) ? ex[par ^ 1][w - 1][1][s][lane] : 0.;
-            e_bot[s] = (w < NW - 1) ? ex[par ^ 1][w + 1][0][s][lane] : 0.;
+            /* the first / last wave has no neighbour: its outermost row is the tile's outermost halo row (or lies outside
+             * the grid), whose results are never used -- it reads its own row instead of branching around the read.
+             * Not in the two shapes that sit at 256 VGPRs: there the eight unconditional reads at the top of the step
+             * lengthen live ranges into scratch spills inside the plane loop (measured 0.68 -> 0.94 ms at 513^3). */
+            if constexpr (S < 4 && RES != 2) {
+                e_top[s] = ex[par ^ 1][w > 0 ? w - 1 : 0][1][s][lane];
+                e_bot[s] = ex[par ^ 1][w < NW - 1 ? w + 1 : NW - 1][0][s][lane];
+            } else {
+                e_top[s] = (w > 0) ? ex[par ^ 1][w - 1][1][s][lane] : 0.;
+                e_bot[s] = (w < NW - 1) ? ex[par ^ 1][w + 1][0][s][lane] : 0.;
+            }
         }
+        long long vbase = g.plane * (long long)(i - S), rbase = g.plane * (long long)(i - ST); /* store planes */
+        asm volatile("" : "+s"(vbase), "+s"(rbase));
         /* which planes may be updated (global boundary planes / slab halos are not) */
         bool pl_upd[STX + 1], acc_ok[STX + 1];
 #pragma unroll
         for (int s = 1; s <= ST; s++) {
             const int q = i - s;
             pl_upd[s] = q >= 1 && q <= g.ni - 2 && (g.ig0 + q) >= 1 && (g.ig0 + q) <= g.N - 2;
-            acc_ok[s] = q >= i_out0 && q < i_out1 && q >= a.acc_lo && q < a.acc_hi; /* planes that enter the norm */
+            /* planes that enter the norm (none without a norm) */
+            if constexpr (RES == 1)
+                acc_ok[s] = (a.partials != nullptr) & (q >= i_out0) & (q < i_out1) & (q >= a.acc_lo) & (q < a.acc_hi);
+            else
+                acc_ok[s] = a.partials && q >= i_out0 && q < i_out1 && q >= a.acc_lo && q < a.acc_hi;
         }
+        /* this step's store planes lie in the output range (wave-uniform, once per step, not once per row) */
+        const bool v_ok = RES == 1 ? (i - S >= i_out0) & (i - S < i_out1) : (i - S >= i_out0 && i - S < i_out1);
+        const bool r_ok = RES == 1 ? (a.r != nullptr) & (i - ST >= i_out0) & (i - ST < i_out1) & pl_upd[ST]
+                                   : (a.r && i - ST >= i_out0 && i - ST < i_out1 && pl_upd[ST]);
+/* wave-uniform tests joined without short-circuit where that is free (one scalar AND instead of a branch per operand);
+ * the restriction shape spills with it (scratch 36 -> 96 bytes, 0.59 -> 1.0 ms), the pure smoothers gain nothing */
+#define MG3D_AND(x, y) (RES == 1 ? ((x) & (y)) : ((x) && (y)))
 
 #pragma unroll
         for (int rr = 0; rr < RJ; rr++) {
@@ -457,46 +501,46 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                 sum = sum + jp;
                 sum = sum + km;
                 sum = sum + kp;
-                const bool updu = row_upd[rr] && pl_upd[s]; /* wave-uniform part of "this point is updated" */
+                /* `&`, not `&&`: a short-circuit on the wave-uniform part turns every update into a scalar branch around
+                 * it (78 branches a step); the select costs nothing and leaves one basic block to schedule */
+                const bool updu = row_upd[rr] & pl_upd[s]; /* wave-uniform part of "this point is updated" */
                 if (s <= S) {
                     const double val = a.sixth * (sum - a.hSq * dd); /* mg_3d.h:438-443 */
-                    nw[s] = (updu && col_upd[X]) ? val : center;
+                    nw[s] = (updu & col_upd[X]) ? val : center;
                     if (RES && s == S) { /* residual of the point just updated: same six neighbours */
                         const double diff = dd - a.invHsq * (sum - 6 * nw[s]); /* mg_3d.h:819-821 */
                         diffs[0] = diff;
                         /* adding +0 leaves a sum of squares unchanged: a select, not a branch */
-                        if (a.partials && updu && row_own[rr] && acc_ok[s])
+                        if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
                             acc += own_upd[X] ? diff * diff : 0.;
                     }
                 } else {
                     const double diff = dd - a.invHsq * (sum - 6 * center); /* mg_3d.h:819-821 */
                     nw[s] = center;
                     diffs[S > 0 ? 1 : s - 1] = diff;
-                    if (a.partials && updu && row_own[rr] && acc_ok[s])
+                    if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
                         acc += own_upd[X] ? diff * diff : 0.;
                 }
             }
             /* ---- stores: v' of plane i-S, r of plane i-S-2 (pairs complete at this step) */
             if constexpr (S > 0) {
-                const int q = i - S;
-                if (q >= i_out0 && q < i_out1 && row_own[rr]) { /* wave-uniform */
+                if (MG3D_AND(v_ok, row_own[rr])) { /* wave-uniform */
                     const double other = last[rr][S - 1][X ^ 1]; /* finished one step ago */
                     double2 o;
                     o.x = X ? other : nw[S];
                     o.y = X ? nw[S] : other;
                     if (pair_own)
-                        st_stream(a.vout + g.plane * q + row_off[rr], o);
+                        st_stream(a.vout + vbase + row_off[rr], o);
                 }
             }
             if constexpr (RES != 0) {
-                const int q = i - ST;
                 /* column X: the residual-only stage now; column X^1: the previous step's diff */
                 double2 o;
                 o.x = X ? rkeep[rr] : diffs[1];
                 o.y = X ? diffs[1] : rkeep[rr];
                 rcur[rr] = o;
-                if (a.r && q >= i_out0 && q < i_out1 && row_own[rr] && row_upd[rr] && pl_upd[ST]) { /* wave-uniform */
-                    double *dst = a.r + g.plane * q + row_off[rr];
+                if (MG3D_AND(MG3D_AND(r_ok, row_own[rr]), row_upd[rr])) { /* wave-uniform */
+                    double *dst = a.r + rbase + row_off[rr];
                     if (own_both)
                         *reinterpret_cast<double2 *>(dst) = o;
                     if (k_edge_tile) { /* boundary entries of r are never written (mg_3d.h:824-825) */
@@ -524,7 +568,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
             const int qq = i - ST - 1, qg = g.ig0 + qq;
             const bool odd = (qg & 1) != 0;
             const double wi = odd ? 0.25 : 0.5;
-            const double2 top = (w > 0) ? rex[par ^ 1][w - 1][lane] : make_double2(0., 0.);
+            const double2 top = rex[par ^ 1][w > 0 ? w - 1 : 0][lane]; /* wave 0: a halo row's sum, never stored */
 #pragma unroll
             for (int c = 0; c < RJ / 2; c++) {
                 const double2 r0 = c == 0 ? top : rlag[2 * c - 1], r1 = rlag[2 * c], r2 = rlag[2 * c + 1];
