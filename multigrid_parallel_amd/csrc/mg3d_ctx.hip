@@ -571,7 +571,10 @@ static int enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters
              * window leaves too few registers for a tile with a useful interior: measured 1.9 ms fused
              * against 0.85 + 0.76 ms split on a 513^3 level) */
             static const bool res4 = getenv("MG3D_FUSE_RES4") && getenv("MG3D_FUSE_RES4")[0] == '1'; /* experiment */
-            const bool res = last && want_res != 0 && (S != 4 || (res4 && coarse == nullptr));
+            /* two passes + residual + restriction in one launch spills (156 bytes of scratch, 1.49 ms at 513^3 against
+             * 0.63 + 0.57 ms as two launches): with a restriction behind it the residual gets its own launch */
+            const bool res = last && want_res != 0 && (S != 4 || (res4 && coarse == nullptr)) &&
+                             !(S == 2 && coarse != nullptr && !k_sweep_fuse_rst2());
             const bool rst = res && coarse != nullptr;
             const bool with_pro = pro != nullptr && passes == 2 * iters; /* first launch only */
             int np;
@@ -677,7 +680,8 @@ extern "C" int mg3d_smooth_restrict(mg3d_ctx *ctx, int level, int iters)
     if (level < 1 || iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_smooth_restrict: bad level/iteration count");
     Level &lev = ctx->lv[level], &lc = ctx->lv[level - 1];
-    CHK(enqueue_smooth_residual(ctx, level, 0, iters, 2, ctx->sumsq_slots - 1, ctx->fused ? &lc : nullptr));
+    CHK(enqueue_smooth_residual(ctx, level, 0, iters, 2, ctx->sumsq_slots - 1, ctx->fused ? &lc : nullptr, nullptr, false,
+                                /* need_norm: only without the fused restriction, whose shapes have no norm */ !ctx->fused));
     k_restrict(lev.g, lev.f[MG3D_R], lc.g, lc.f[MG3D_D], ctx->stream, -1, -1, ctx->fused);
     return launch_ok("mg3d_smooth_restrict");
 }

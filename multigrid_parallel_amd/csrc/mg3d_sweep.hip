@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
              * the grid), whose results are never used -- it reads its own row instead of branching around the read.
              * Not in the two shapes that sit at 256 VGPRs: there the eight unconditional reads at the top of the step
              * lengthen live ranges into scratch spills inside the plane loop (measured 0.68 -> 0.94 ms at 513^3). */
-            if constexpr (S < 4 && RES != 2) {
+            if constexpr (S < 4 && (RES != 2 || PF == 1)) {
                 e_top[s] = ex[par ^ 1][w > 0 ? w - 1 : 0][1][s][lane];
                 e_bot[s] = ex[par ^ 1][w < NW - 1 ? w + 1 : NW - 1][0][s][lane];
             } else {
@@ -511,15 +511,17 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                         const double diff = dd - a.invHsq * (sum - 6 * nw[s]); /* mg_3d.h:819-821 */
                         diffs[0] = diff;
                         /* adding +0 leaves a sum of squares unchanged: a select, not a branch */
-                        if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
-                            acc += own_upd[X] ? diff * diff : 0.;
+                        if constexpr (RES == 1)
+                            if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
+                                acc += own_upd[X] ? diff * diff : 0.;
                     }
                 } else {
                     const double diff = dd - a.invHsq * (sum - 6 * center); /* mg_3d.h:819-821 */
                     nw[s] = center;
                     diffs[S > 0 ? 1 : s - 1] = diff;
-                    if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
-                        acc += own_upd[X] ? diff * diff : 0.;
+                    if constexpr (RES == 1)
+                        if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
+                            acc += own_upd[X] ? diff * diff : 0.;
                 }
             }
             /* ---- stores: v' of plane i-S, r of plane i-S-2 (pairs complete at this step) */
@@ -539,7 +541,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                 o.x = X ? rkeep[rr] : diffs[1];
                 o.y = X ? diffs[1] : rkeep[rr];
                 rcur[rr] = o;
-                if (MG3D_AND(MG3D_AND(r_ok, row_own[rr]), row_upd[rr])) { /* wave-uniform */
+                if (RES == 1 && MG3D_AND(MG3D_AND(r_ok, row_own[rr]), row_upd[rr])) { /* wave-uniform */
                     double *dst = a.r + rbase + row_off[rr];
                     if (own_both)
                         *reinterpret_cast<double2 *>(dst) = o;
@@ -635,7 +637,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         step(pl, std::integral_constant<int, 0>{});
     } /* segments */
 
-    if (RES && a.partials) {
+    if (RES == 1 && a.partials) {
 #pragma unroll
         for (int off = WAVE / 2; off > 0; off >>= 1)
             acc += __shfl_down(acc, off, WAVE);
@@ -813,12 +815,18 @@ template <> int dispatch<0, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
 template <> int dispatch<0, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(0, 2, 4, 8, 1) TRY(0, 2, 4, 8, 2)
-    DFLT(0, 2, 4, 8, 2)
+    DFLT(0, 2, 4, 8, 1)
 }
 template <> int dispatch<2, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(2, 2, 4, 8, 1)
     DFLT(2, 2, 4, 8, 1)
+}
+
+bool k_sweep_fuse_rst2() /* MG3D_FUSE_RST2=1: keep the one-launch shape for two passes + residual + restriction */
+{
+    const char *e = getenv("MG3D_FUSE_RST2"); /* read per stage, so that a test can compare both routes in one process */
+    return e && e[0] == '1';
 }
 
 int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
@@ -847,6 +855,11 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
     a.vin = vin;
     a.d = d;
     a.vout = vout;
+    /* the restricting shapes (RES == 2) produce neither a stored r nor the norm: their callers never ask for either,
+     * and without that code the residual + restriction launch has 60 fewer scalar instructions and 10 fewer branches a
+     * step */
+    if (dc && (r || partials))
+        return -1;
     a.r = r;
     a.partials = partials;
     a.hSq = h * h;           /* mg_3d.h:644 */
@@ -863,7 +876,7 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
         return -1;
     }
     if (dc && S == 0 && residual)
-        return dispatch<0, 2>(a, env_cfg({4, 8, 2}), max_partials, s);
+        return dispatch<0, 2>(a, env_cfg({4, 8, 1}), max_partials, s);
     if (dc && S == 2 && residual)
         return dispatch<2, 2>(a, env_cfg({4, 8, 1}), max_partials, s);
     if (dc)

@@ -37,6 +37,21 @@ def test_slab_vcycles_match_single_domain(monkeypatch, c, L, nu, P, min_planes):
     np.testing.assert_allclose(norms, want_norms, rtol=1e-11, atol=0)
 
 
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_slab_one_sweep_cycles_both_down_leg_routes(monkeypatch, fuse):
+    """V(1,1) on slabs: the down-leg's two passes + residual + restriction as two launches (default) or as the one-launch
+    shape (MG3D_FUSE_RST2=1) -- both bit-identical to the single domain."""
+    monkeypatch.setenv("MG3D_SLAB_MIN_PLANES", "8")
+    monkeypatch.setenv("MG3D_FUSE_RST2", fuse)
+    c, L, nu, P = 9, 5, 1, 4
+    want_norms, want_u = single(c, L, nu, 5)
+    with M.DistSolver(c, L, nu, nranks=P) as d:
+        d.setup_test_problem()
+        norms = d.vcycles(5)
+        assert np.array_equal(d.download(MG3D_U, L - 1), want_u)
+    np.testing.assert_allclose(norms, want_norms, rtol=1e-11, atol=0)
+
+
 def test_slab_intermediate_levels_match_single_domain(monkeypatch):
     monkeypatch.setenv("MG3D_SLAB_MIN_PLANES", "8")
     c, L, nu, P = 9, 5, 2, 4

@@ -572,3 +572,22 @@ def test_single_workgroup_level_equals_the_generic_kernels(monkeypatch, c, L, nu
     want_norms, want_u, _, _ = O.run_problem(c, L, nu, 4)
     assert np.array_equal(res[0][1][-1], want_u)
     np.testing.assert_allclose(res[0][0], want_norms, rtol=norm_rtol((c - 1) * (1 << (L - 1)) + 1))
+
+
+@pytest.mark.parametrize("c,L", [(9, 4), (5, 5), (3, 6)])
+def test_one_sweep_down_leg_two_launches_equal_the_fused_shape(monkeypatch, c, L):
+    """V(1,1): two colour passes + residual + restriction run as two launches by default (the one-launch shape spills
+    registers); MG3D_FUSE_RST2=1 keeps the one-launch shape.  Same bits, and both equal the oracle."""
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MG3D_FUSE_RST2", flag)
+        with M.Solver(c, L, 1) as s:
+            s.setup_test_problem()
+            norms = s.vcycles(4)
+            res.append((norms, [s.download(MG3D_U, l) for l in range(L)], [s.download(MG3D_D, l) for l in range(L - 1)]))
+    assert np.array_equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert np.array_equal(a, b)
+    want_norms, want_u, _, _ = O.run_problem(c, L, 1, 4)
+    assert np.array_equal(res[0][1][-1], want_u)
+    np.testing.assert_allclose(res[0][0], want_norms, rtol=norm_rtol((c - 1) * (1 << (L - 1)) + 1))
