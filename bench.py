@@ -333,6 +333,8 @@ def main():
         if dist.is_initialized():
             dist.broadcast_object_list(uid, src=0)
         solver = M.DistSolver(c, L, nu, rank=rank, nranks=world, unique_id=uid[0], device=local_rank)
+        solver.setup_test_problem()
+        solver.vcycles(1)  # priming: the sweep launcher measures its chunk lengths on first use; the problem is set up again
         init = solver.setup_test_problem()
         warm_norms = solver.vcycles(args.warmup)
         barrier(solver)
@@ -418,6 +420,11 @@ def main():
         return
 
     solver = M.Solver(c, L, nu)
+    # priming: the sweep launcher times a few chunk lengths the first time a kernel shape meets a level
+    # (csrc/mg3d_sweep.hip); one cycle, then the problem is set up afresh -- kept out of the warm-up so that --warmup 0
+    # is valid and the residual history starts at the initial guess
+    solver.setup_test_problem()
+    solver.vcycles(1)
     solver.setup_test_problem()
     init = solver.get_initial_residual()
 

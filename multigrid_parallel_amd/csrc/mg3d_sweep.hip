@@ -46,6 +46,12 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #define WAVE 64
 
@@ -698,54 +704,75 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
     const int ncu = device_cus();
     const long long T = (long long)a.ntj * a.ntk;
     const int ovh = Sh::HI + Sh::ST + (RES == 2 ? 2 : 0) + 1;
-    int best_nci = 1;
-    double best_cost = 1e30;
-    for (int nci = 1; nci <= 64 && nci <= nout; nci++) {
-        const int ci = (nout + nci - 1) / nci;
-        if (nci > 1 && ci < 2)
-            break;
+    auto model_cost = [&](int ci) -> double { /* in steps; < 0: not launchable */
         const long long blocks = T * ((nout + ci - 1) / ci);
         if (a.partials && blocks > max_partials)
-            break;
+            return -1.;
         const double steps = (double)(ci + ovh);
         /* the four-pass launch saturates the memory system with ~80 % of the CUs streaming; the shorter pipelines
          * (two passes + residual, residual + restriction, prolongation + two passes) spend more of a step computing
          * and keep scaling to all of them */
         const double sat = S >= 4 && RES == 0 ? 0.8 : 1.0;
         const double crit = (double)((blocks + ncu - 1) / ncu) * steps, bw = (double)blocks * steps / (sat * ncu);
-        const double cost = crit > bw ? crit : bw;
+        return crit > bw ? crit : bw;
+    };
+    int best_ci = nout;
+    double best_cost = 1e30;
+    for (int nci = 1; nci <= 64 && nci <= nout; nci++) {
+        const int ci = (nout + nci - 1) / nci;
+        if (nci > 1 && ci < 2)
+            break;
+        const double cost = model_cost(ci);
+        if (cost < 0)
+            break;
         if (cost < best_cost * 0.97) {
             best_cost = cost;
-            best_nci = nci;
+            best_ci = ci;
         }
     }
-    a.CI = (nout + best_nci - 1) / best_nci;
-    if (S >= 4 && RES == 0 && T < ncu && T * 8 > ncu) {
-        /* The four-pass launch is held back by the CUs a whole number of chunk layers leaves idle (513^3: 110 tile
-         * columns, two layers = 220 of 256 CUs) rather than by the memory system: m full layers of x planes and a
-         * short tail chunk that the left-over CUs work off in ceil(T / left) turns, sized so that both finish
-         * together (231 + 231 + 51 planes: 240 steps instead of 266; measured 0.751 against 0.779 ms).  The shorter
-         * pipelines do not gain from it (measured), they keep equal chunks. */
+    /* A short tail chunk: where a whole number of chunk layers leaves CUs idle (513^3, four passes: 110 tile columns,
+     * two layers = 220 of 256 CUs), m full layers of x planes and a tail chunk that the left-over CUs work off in
+     * ceil(T / left) turns, sized so that both finish together (231 + 231 + 51 planes: 240 steps instead of 266;
+     * 0.675 against 0.700 ms).  It pays at 385^3 and 513^3 and costs 10-25 % at 257^3, 449^3 and 641^3 -- no rule in
+     * T, the left-over CUs or the turns separates the two, so it is one more candidate for the measurement below and
+     * the model's choice only for the size it was found on. */
+    int tail_ci = 0;
+    if (T < ncu && T * 8 > ncu) {
         const int m = ncu / (int)T, left = ncu - m * (int)T;
         if (left * 8 >= T) {
             const int turns = ((int)T + left - 1) / left;
             const int x = (turns * (nout + ovh) - ovh + m * turns) / (1 + m * turns);
-            if (x > 0 && nout - m * x > 0 && (double)(x + ovh) < 0.97 * best_cost)
-                a.CI = x;
+            if (x > 0 && nout - m * x > 0 && (double)(x + ovh) < 0.97 * best_cost && model_cost(x) >= 0)
+                tail_ci = x;
         }
     }
+    const char *te = getenv("MG3D_SWEEP_TAIL"); /* 0: never, 1: whenever it is shorter; unset: four passes at 4 turns */
+    const int tail_mode = te ? atoi(te) : 2;
+    a.CI = best_ci;
+    if (tail_ci && (tail_mode == 1 || (tail_mode == 2 && S >= 4 && RES == 0 && ((int)T + (ncu % (int)T) - 1) / (ncu % (int)T) >= 4)))
+        a.CI = tail_ci;
+    bool forced = false;
     if (const char *e = getenv("MG3D_SWEEP_CI"))
-        if (atoi(e) > 0)
+        if (atoi(e) > 0) {
             a.CI = atoi(e) < nout ? atoi(e) : nout;
-    long long nb = T * ((nout + a.CI - 1) / a.CI);
+            forced = true;
+        }
     a.snap = 0;
+    long long nb = 0;
     /* XCD grouping: the blocks of one XCD group (blockIdx % 8) take a contiguous run of tile columns, so that
      * neighbouring tile columns mostly share an L2 (a tenth to a quarter fewer bytes from the fabric).  One round of
      * blocks: renumber the whole grid (1); several rounds: inside every chunk's layer (2) -- renumbering the whole
      * grid would scatter the first round over all chunks and break the lock-step. */
-    a.xcd_remap = nb < 64 ? 0 : nb <= ncu ? 1 : 2;
-    if (const char *e = getenv("MG3D_XCD")) /* 0 off, 1 whole grid (one round), 2 per chunk layer, 3: 1 or 2 by rounds */
-        a.xcd_remap = atoi(e) == 3 ? (nb < 64 ? 0 : nb <= ncu ? 1 : 2) : atoi(e);
+    auto set_ci = [&](int ci) {
+        a.CI = ci;
+        nb = T * ((nout + ci - 1) / ci);
+        a.xcd_remap = nb < 64 ? 0 : nb <= ncu ? 1 : 2;
+        if (const char *e = getenv("MG3D_XCD")) /* 0 off, 1 whole grid (one round), 2 per chunk layer, 3: 1 or 2 by rounds */
+            a.xcd_remap = atoi(e) == 3 ? (nb < 64 ? 0 : nb <= ncu ? 1 : 2) : atoi(e);
+    };
+    auto launch = [&]() {
+        hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
+    };
     if (getenv("MG3D_SWEEP_BALANCED") && getenv("MG3D_SWEEP_BALANCED")[0] == '1') {
         /* experiment: equal shares of the linearised (tile column, plane) space, one block per CU, no lock-step */
         a.CI = 0;
@@ -753,10 +780,87 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
         if ((long long)T * nout / nb < 4)
             nb = (long long)T * nout / 4 > 0 ? (long long)T * nout / 4 : 1;
         a.snap = ((long long)T * nout / nb >= 4 * ovh) ? ovh : 0;
+        a.xcd_remap = nb < 64 ? 0 : 1;
+        if (a.partials && nb > max_partials)
+            return -1;
+        launch();
+        return (int)nb;
+    }
+    /* Measured choice.  The model above ranks chunk lengths by steps; what a step costs depends on how many CUs stream
+     * at once and on how well the chunks keep in lock-step, which it does not know.  The first launch of a shape on a
+     * level geometry therefore times the model's best few candidates (the launch is idempotent: it reads u, d, writes
+     * the other buffer; every chunking gives the same bits) and the fastest is remembered for the process.
+     * MG3D_SWEEP_TUNE=0 keeps the model's choice. */
+    const char *tune_env = getenv("MG3D_SWEEP_TUNE");
+    const bool tune_on = !(tune_env && tune_env[0] == '0');
+    if (!forced && tune_on && T * nout >= 1024) {
+        struct Key {
+            int v[12];
+            bool operator<(const Key &o) const { return memcmp(v, o.v, sizeof v) < 0; }
+        };
+        const Key key = {{g.ni, g.nj, g.nk, g.N, g.ig0 & 1, a.i_lo, a.i_hi, a.vin != nullptr, a.partials != nullptr,
+                          a.r != nullptr, a.vk, max_partials}};
+        static std::mutex mu;
+        static std::map<Key, int> tuned;
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = tuned.find(key);
+        if (it == tuned.end()) {
+            std::vector<int> cand;
+            auto add = [&](int ci) {
+                if (ci >= 1 && ci <= nout && model_cost(ci) >= 0 && std::find(cand.begin(), cand.end(), ci) == cand.end())
+                    cand.push_back(ci);
+            };
+            add(a.CI);
+            add(best_ci);
+            add(tail_ci);
+            for (int nci = 1; nci <= 64 && nci <= nout && cand.size() < 10; nci++) {
+                const int ci = (nout + nci - 1) / nci;
+                if (nci > 1 && ci < 2)
+                    break;
+                const double c = model_cost(ci);
+                if (c >= 0 && c <= 1.35 * best_cost)
+                    add(ci);
+            }
+            const int model_ci = a.CI;
+            int pick = model_ci;
+            if (cand.size() > 1) {
+                hipEvent_t e0, e1;
+                if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                    float best_ms = 1e30f;
+                    for (int ci : cand) {
+                        set_ci(ci);
+                        float ms_min = 1e30f;
+                        for (int rep = 0; rep < 3; rep++) { /* the first one also warms the instruction cache */
+                            float ms = 0.f;
+                            (void)hipEventRecord(e0, s);
+                            launch();
+                            (void)hipEventRecord(e1, s);
+                            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                                ms = 1e30f;
+                            if (rep > 0 && ms < ms_min)
+                                ms_min = ms;
+                        }
+                        if (ms_min < best_ms) {
+                            best_ms = ms_min;
+                            pick = ci;
+                        }
+                    }
+                    (void)hipEventDestroy(e0);
+                    (void)hipEventDestroy(e1);
+                }
+            }
+            it = tuned.emplace(key, pick).first;
+            if (getenv("MG3D_SWEEP_TUNE_LOG"))
+                fprintf(stderr, "mg3d sweep<%d,%d,%d,%d,%d,%d> %dx%dx%d planes [%d,%d): %zu candidates, chunk %d (model %d)\n", S,
+                        RES, RJ, NW, PF, (int)PRO, g.ni, g.nj, g.nk, a.i_lo, a.i_hi, cand.size(), pick, model_ci);
+        }
+        set_ci(it->second);
+    } else {
+        set_ci(a.CI);
     }
     if (a.partials && nb > max_partials)
         return -1;
-    hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
+    launch();
     return (int)nb;
 }
 

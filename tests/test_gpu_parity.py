@@ -591,3 +591,24 @@ def test_one_sweep_down_leg_two_launches_equal_the_fused_shape(monkeypatch, c, L
     want_norms, want_u, _, _ = O.run_problem(c, L, 1, 4)
     assert np.array_equal(res[0][1][-1], want_u)
     np.testing.assert_allclose(res[0][0], want_norms, rtol=norm_rtol((c - 1) * (1 << (L - 1)) + 1))
+
+
+def test_measured_chunk_length_changes_no_bit(monkeypatch):
+    """The first launch of a sweep shape on a level times a few chunk lengths and keeps the fastest (MG3D_SWEEP_TUNE=0:
+    the cost model's choice; MG3D_SWEEP_CI: a fixed one).  Chunking is a work distribution only: same grid values (the norm is a sum of per-block partial sums).""" 
+    c, L, nu = 9, 5, 2  # 129^3: large enough for the measurement to run
+    res = []
+    for env in ({"MG3D_SWEEP_TUNE": "0"}, {}, {"MG3D_SWEEP_CI": "5"}, {"MG3D_SWEEP_TAIL": "1", "MG3D_SWEEP_TUNE": "0"}):
+        for k in ("MG3D_SWEEP_TUNE", "MG3D_SWEEP_CI", "MG3D_SWEEP_TAIL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with M.Solver(c, L, nu) as s:
+            s.setup_test_problem()
+            norms = s.vcycles(3)
+            res.append((norms, s.download(MG3D_U, L - 1), s.download(MG3D_D, L - 2)))
+    for r in res[1:]:
+        assert np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
+        np.testing.assert_allclose(r[0], res[0][0], rtol=1e-13)  # one partial sum per block: the grouping differs
+    want_norms, want_u, _, _ = O.run_problem(c, L, nu, 3)
+    assert np.array_equal(res[0][1], want_u)
