@@ -763,12 +763,13 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
      * neighbouring tile columns mostly share an L2 (a tenth to a quarter fewer bytes from the fabric).  One round of
      * blocks: renumber the whole grid (1); several rounds: inside every chunk's layer (2) -- renumbering the whole
      * grid would scatter the first round over all chunks and break the lock-step. */
+    const char *xcd_env = getenv("MG3D_XCD"); /* 0 off, 1 whole grid (one round), 2 per chunk layer, 3: 1 or 2 by rounds */
+    const bool xcd_forced = xcd_env && atoi(xcd_env) != 3;
     auto set_ci = [&](int ci) {
         a.CI = ci;
         nb = T * ((nout + ci - 1) / ci);
-        a.xcd_remap = nb < 64 ? 0 : nb <= ncu ? 1 : 2;
-        if (const char *e = getenv("MG3D_XCD")) /* 0 off, 1 whole grid (one round), 2 per chunk layer, 3: 1 or 2 by rounds */
-            a.xcd_remap = atoi(e) == 3 ? (nb < 64 ? 0 : nb <= ncu ? 1 : 2) : atoi(e);
+        /* (measured in isolation, grouping 0 sometimes wins by 2 %; inside the cycle it then loses 5 %: not tuned) */
+        a.xcd_remap = xcd_forced ? atoi(xcd_env) : nb < 64 ? 0 : nb <= ncu ? 1 : 2;
     };
     auto launch = [&]() {
         hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
@@ -801,7 +802,7 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
         const Key key = {{g.ni, g.nj, g.nk, g.N, g.ig0 & 1, a.i_lo, a.i_hi, a.vin != nullptr, a.partials != nullptr,
                           a.r != nullptr, a.vk, max_partials}};
         static std::mutex mu;
-        static std::map<Key, int> tuned;
+        static std::map<Key, int> tuned; /* chunk length */
         std::lock_guard<std::mutex> lock(mu);
         auto it = tuned.find(key);
         if (it == tuned.end()) {
@@ -823,36 +824,38 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
             }
             const int model_ci = a.CI;
             int pick = model_ci;
-            if (cand.size() > 1) {
-                hipEvent_t e0, e1;
-                if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-                    float best_ms = 1e30f;
-                    for (int ci : cand) {
-                        set_ci(ci);
-                        float ms_min = 1e30f;
-                        for (int rep = 0; rep < 3; rep++) { /* the first one also warms the instruction cache */
-                            float ms = 0.f;
-                            (void)hipEventRecord(e0, s);
-                            launch();
-                            (void)hipEventRecord(e1, s);
-                            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
-                                ms = 1e30f;
-                            if (rep > 0 && ms < ms_min)
-                                ms_min = ms;
-                        }
-                        if (ms_min < best_ms) {
-                            best_ms = ms_min;
-                            pick = ci;
-                        }
+            hipEvent_t e0, e1;
+            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                auto timed = [&]() { /* best of two after one launch that also warms the instruction cache */
+                    float ms_min = 1e30f;
+                    for (int rep = 0; rep < 3; rep++) {
+                        float ms = 0.f;
+                        (void)hipEventRecord(e0, s);
+                        launch();
+                        (void)hipEventRecord(e1, s);
+                        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                            ms = 1e30f;
+                        if (rep > 0 && ms < ms_min)
+                            ms_min = ms;
                     }
-                    (void)hipEventDestroy(e0);
-                    (void)hipEventDestroy(e1);
+                    return ms_min;
+                };
+                float best_ms = 1e30f;
+                for (int ci : cand) {
+                    set_ci(ci);
+                    const float ms = timed();
+                    if (ms < best_ms) {
+                        best_ms = ms;
+                        pick = ci;
+                    }
                 }
+                (void)hipEventDestroy(e0);
+                (void)hipEventDestroy(e1);
             }
             it = tuned.emplace(key, pick).first;
             if (getenv("MG3D_SWEEP_TUNE_LOG"))
-                fprintf(stderr, "mg3d sweep<%d,%d,%d,%d,%d,%d> %dx%dx%d planes [%d,%d): %zu candidates, chunk %d (model %d)\n", S,
-                        RES, RJ, NW, PF, (int)PRO, g.ni, g.nj, g.nk, a.i_lo, a.i_hi, cand.size(), pick, model_ci);
+                fprintf(stderr, "mg3d sweep<%d,%d,%d,%d,%d,%d> %dx%dx%d planes [%d,%d): %zu candidates, chunk %d (model %d)\n",
+                        S, RES, RJ, NW, PF, (int)PRO, g.ni, g.nj, g.nk, a.i_lo, a.i_hi, cand.size(), pick, model_ci);
         }
         set_ci(it->second);
     } else {
