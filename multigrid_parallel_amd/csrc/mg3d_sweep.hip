@@ -752,11 +752,14 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
     if (tail_ci && (tail_mode == 1 || (tail_mode == 2 && S >= 4 && RES == 0 && ((int)T + (ncu % (int)T) - 1) / (ncu % (int)T) >= 4)))
         a.CI = tail_ci;
     bool forced = false;
-    if (const char *e = getenv("MG3D_SWEEP_CI"))
-        if (atoi(e) > 0) {
-            a.CI = atoi(e) < nout ? atoi(e) : nout;
-            forced = true;
-        }
+    char ci_shape[32]; /* MG3D_SWEEP_CI: every shape; MG3D_SWEEP_CI_<S><RES>[P]: one shape (e.g. _02 residual + restriction) */
+    snprintf(ci_shape, sizeof ci_shape, "MG3D_SWEEP_CI_%d%d%s", S, RES, PRO ? "P" : "");
+    for (const char *name : {(const char *)ci_shape, "MG3D_SWEEP_CI"})
+        if (const char *e = getenv(name))
+            if (atoi(e) > 0 && !forced) {
+                a.CI = atoi(e) < nout ? atoi(e) : nout;
+                forced = true;
+            }
     a.snap = 0;
     long long nb = 0;
     /* XCD grouping: the blocks of one XCD group (blockIdx % 8) take a contiguous run of tile columns, so that
