@@ -573,7 +573,11 @@ static int enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters
             static const bool res4 = getenv("MG3D_FUSE_RES4") && getenv("MG3D_FUSE_RES4")[0] == '1'; /* experiment */
             /* two passes + residual + restriction in one launch spills (156 bytes of scratch, 1.49 ms at 513^3 against
              * 0.63 + 0.57 ms as two launches): with a restriction behind it the residual gets its own launch */
-            const bool res = last && want_res != 0 && (S != 4 || (res4 && coarse == nullptr)) &&
+            /* small levels (<= MG3D_FUSE_LEG_MAX points per side): the whole down-leg -- four passes, residual,
+             * restriction -- as one launch of the two-rows-per-thread shape: it wastes three quarters of its rows
+             * and saves a launch where launches are paid in latency, not in bytes */
+            const bool leg4 = S == 4 && coarse != nullptr && !need_norm && want_res != 0 && l.g.N <= k_sweep_fuse_leg_max();
+            const bool res = last && want_res != 0 && (S != 4 || (res4 && coarse == nullptr) || leg4) &&
                              !(S == 2 && coarse != nullptr && !k_sweep_fuse_rst2());
             const bool rst = res && coarse != nullptr;
             const bool with_pro = pro != nullptr && passes == 2 * iters; /* first launch only */
@@ -620,8 +624,10 @@ static int enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters
 }
 
 /* can the prolongation ride on the first smoothing launch?  (needs a smoothing-only first launch) */
-static bool pro_fusable(const mg3d_ctx *ctx, int iters, int want_res)
+static bool pro_fusable(const mg3d_ctx *ctx, int iters, int want_res, int level)
 {
+    /* small levels: the two-rows-per-thread four-pass shape has the registers for the prolongation (k_sweep) */
+    const bool small = ctx->lv[level].g.N <= k_sweep_fuse_leg_max() && 2 * iters == 4 && want_res == 0;
     /* On a 4-pass first launch it is opt-in (MG3D_PRO_FUSE=1): bit-identical, but measured SLOWER on MI355X at 513^3 --
      * the 4-pass sweep already uses 249 VGPRs, the prologue spills 44 dwords and the launch takes 1.48 ms against
      * 0.85 ms (sweep) + 0.56 ms (separate prolongation kernel).  The 2-pass first launch of a split stage takes it
@@ -630,7 +636,7 @@ static bool pro_fusable(const mg3d_ctx *ctx, int iters, int want_res)
     if (!ctx->fused || iters < 1)
         return false;
     const bool sp = split_up_leg(iters, want_res);
-    if (!on && !sp)
+    if (!on && !sp && !small)
         return false;
     const int first = (2 * iters >= 4 && !sp) ? 4 : 2;
     const bool first_has_res = want_res != 0 && first == 2 && 2 * iters == 2;
@@ -805,7 +811,7 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
             continue;
         }
         const int want_norm = l == q ? 1 : 0;
-        const bool pro = pro_fusable(ctx, ctx->iters, want_norm);
+        const bool pro = pro_fusable(ctx, ctx->iters, want_norm, l);
         {
             StageScope t(ctx, l, MG3D_ST_PROLONG); /* :1331; ~0 s when folded into the smoother's loads */
             if (!pro) {

@@ -902,6 +902,7 @@ template <> int dispatch<4, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
 template <> int dispatch<4, 0>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(4, 0, 8, 4, 1) TRY(4, 0, 6, 4, 2) TRY(4, 0, 6, 4, 3) TRY(4, 0, 4, 8, 1) TRY(4, 0, 4, 8, 2)
+    TRY(4, 0, 2, 8, 2) TRY(4, 0, 2, 8, 4)
     DFLT(4, 0, 4, 8, 1)
 }
 template <> int dispatch<2, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
@@ -912,6 +913,7 @@ template <> int dispatch<2, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
 template <> int dispatch<2, 0>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(2, 0, 6, 8, 1) TRY(2, 0, 8, 4, 2) TRY(2, 0, 4, 8, 1) TRY(2, 0, 4, 8, 2) TRY(2, 0, 4, 8, 3)
+    TRY(2, 0, 2, 8, 4)
     DFLT(2, 0, 4, 8, 1)
 }
 template <> int dispatch<0, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
@@ -924,13 +926,33 @@ template <> int dispatch<0, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
  * partial sums written (0 when no norm was requested), -1 if the shape is unsupported. */
 template <> int dispatch<0, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
-    TRY(0, 2, 4, 8, 1) TRY(0, 2, 4, 8, 2)
+    TRY(0, 2, 4, 8, 1) TRY(0, 2, 4, 8, 2) TRY(0, 2, 2, 8, 2) TRY(0, 2, 2, 8, 4)
     DFLT(0, 2, 4, 8, 1)
+}
+template <> int dispatch<4, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+{
+    /* the whole down-leg of a level in ONE launch.  The six-stage window only fits two rows per thread (16-row tiles
+     * with a halo of 6: four owned rows): a quarter of the rows it computes are kept -- for the levels where a launch
+     * is paid in pipeline steps and microseconds of launch latency, not in bytes */
+    TRY(4, 2, 2, 8, 1) TRY(4, 2, 2, 8, 2)
+    DFLT(4, 2, 2, 8, 2)
 }
 template <> int dispatch<2, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(2, 2, 4, 8, 1)
     DFLT(2, 2, 4, 8, 1)
+}
+
+int k_sweep_small_max() /* levels of at most this many points per side use the two-rows-per-thread shapes */
+{
+    const char *e = getenv("MG3D_SMALL_MAX"); /* 0: never */
+    return e ? atoi(e) : 65;
+}
+
+int k_sweep_fuse_leg_max() /* levels of at most this many points per side run a whole leg of the cycle as ONE launch */
+{
+    const char *e = getenv("MG3D_FUSE_LEG_MAX"); /* 0: never */
+    return e ? atoi(e) : 65;
 }
 
 bool k_sweep_fuse_rst2() /* MG3D_FUSE_RST2=1: keep the one-launch shape for two passes + residual + restriction */
@@ -979,26 +1001,33 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
     if (ec) { /* prolongation fused into the input: 4- and 2-pass smoothing launches */
         if (dc || residual || (g.nj & 1) == 0)
             return -1;
-        if (S == 4)
-            return launch_sweep<4, 0, 4, 8, 1, true>(a, max_partials, s);
+        if (S == 4) /* small levels: two rows per thread (no spills, 8 owned rows of 16); else the opt-in four-row shape */
+            return g.N <= k_sweep_fuse_leg_max() ? launch_sweep<4, 0, 2, 8, 2, true>(a, max_partials, s)
+                                                 : launch_sweep<4, 0, 4, 8, 1, true>(a, max_partials, s);
         if (S == 2)
             return launch_sweep<2, 0, 4, 8, 1, true>(a, max_partials, s);
         return -1;
     }
+    /* Levels of at most 65^3 points: a step costs a global-load latency (~1.4 us with one plane in flight), not
+     * bandwidth, and only a few tiles exist anyway -- two rows per thread leave the registers for two planes in flight
+     * (33^3: four passes 20 -> 13 us, residual + restriction 15 -> 12 us; at 257^3 the same shapes are 40 % slower). */
+    const bool small = g.N <= k_sweep_small_max();
     if (dc && S == 0 && residual)
-        return dispatch<0, 2>(a, env_cfg({4, 8, 1}), max_partials, s);
+        return dispatch<0, 2>(a, env_cfg(small ? SweepCfg{2, 8, 2} : SweepCfg{4, 8, 1}), max_partials, s);
     if (dc && S == 2 && residual)
         return dispatch<2, 2>(a, env_cfg({4, 8, 1}), max_partials, s);
+    if (dc && S == 4 && residual)
+        return dispatch<4, 2>(a, env_cfg({2, 8, 2}), max_partials, s);
     if (dc)
         return -1;
     if (S == 4 && residual)
         return dispatch<4, 1>(a, env_cfg({6, 4, 2}), max_partials, s);
     if (S == 4 && !residual)
-        return dispatch<4, 0>(a, env_cfg({4, 8, 1}), max_partials, s);
+        return dispatch<4, 0>(a, env_cfg(small ? SweepCfg{2, 8, 2} : SweepCfg{4, 8, 1}), max_partials, s);
     if (S == 2 && residual)
         return dispatch<2, 1>(a, env_cfg({4, 8, 1}), max_partials, s);
     if (S == 2 && !residual)
-        return dispatch<2, 0>(a, env_cfg({4, 8, 1}), max_partials, s);
+        return dispatch<2, 0>(a, env_cfg(small ? SweepCfg{2, 8, 4} : SweepCfg{4, 8, 1}), max_partials, s);
     if (S == 0 && residual)
         return dispatch<0, 1>(a, env_cfg({4, 8, 1}), max_partials, s);
     return -1;

@@ -67,6 +67,9 @@ def lib():
         L.orc_es_dirichlet_xl.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
         L.orc_max_threads.restype = C.c_int
         L.orc_set_threads.argtypes = [C.c_int]
+        # one thread unless a test asks for more: on a box whose core count exceeds this process's CPU share (the GPU
+        # box: 256 cores, 16 granted) the OpenMP default makes every parallel region of a small problem take milliseconds
+        L.orc_set_threads(1)
         _lib = L
     return _lib
 

@@ -612,3 +612,27 @@ def test_measured_chunk_length_changes_no_bit(monkeypatch):
         np.testing.assert_allclose(r[0], res[0][0], rtol=1e-13)  # one partial sum per block: the grouping differs
     want_norms, want_u, _, _ = O.run_problem(c, L, nu, 3)
     assert np.array_equal(res[0][1], want_u)
+
+
+@pytest.mark.parametrize("c,L,nu", [(9, 4, 2), (5, 5, 2), (3, 6, 2), (7, 4, 2), (9, 5, 2), (6, 4, 3)])
+@pytest.mark.parametrize("small,legs", [("0", "0"), ("65", "0"), ("0", "65"), ("1000", "1000")])
+def test_small_level_policy_changes_no_bit(monkeypatch, c, L, nu, small, legs):
+    """Levels of at most 65^3 points run the two-rows-per-thread shapes with two planes in flight (MG3D_SMALL_MAX) and,
+    for V(2,2), each leg of the cycle as ONE launch (four passes + residual + restriction; prolongation + four passes:
+    MG3D_FUSE_LEG_MAX).  Either policy off, both off, or both forced onto every level: the same bits as the default, and
+    the default equals the oracle."""
+    res = []
+    for env in ({}, {"MG3D_SMALL_MAX": small, "MG3D_FUSE_LEG_MAX": legs}):
+        for k in ("MG3D_SMALL_MAX", "MG3D_FUSE_LEG_MAX"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with M.Solver(c, L, nu) as s:
+            s.setup_test_problem()
+            norms = s.vcycles(3)
+            res.append((norms, [s.download(MG3D_U, l) for l in range(L)], [s.download(MG3D_D, l) for l in range(L - 1)]))
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-13)
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert np.array_equal(a, b)
+    want_norms, want_u, _, _ = O.run_problem(c, L, nu, 3)
+    assert np.array_equal(res[0][1][-1], want_u)
