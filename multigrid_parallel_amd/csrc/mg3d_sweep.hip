@@ -154,7 +154,7 @@ __device__ __forceinline__ void st_stream(double *p, double2 o)
 #endif
 }
 
-template <int S, int RES, int RJ, int NW, int PF, bool PRO>
+template <int S, int RES, int RJ, int NW, int PF, bool PRO, bool RST>
 __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 {
     using Sh = SweepShape<S, RES>;
@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                         st_stream(a.vout + vbase + row_off[rr], o);
                 }
             }
-            if constexpr (RES != 0) {
+            if constexpr (RES == 2 || (RES == 1 && RST)) { /* RST = false: the norm only, r is not assembled */
                 /* column X: the residual-only stage now; column X^1: the previous step's diff */
                 double2 o;
                 o.x = X ? rkeep[rr] : diffs[1];
@@ -674,7 +674,7 @@ static int device_cus()
     return n;
 }
 
-template <int S, int RES, int RJ, int NW, int PF, bool PRO = false>
+template <int S, int RES, int RJ, int NW, int PF, bool PRO = false, bool RST = true>
 static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
 {
     using Sh = SweepShape<S, RES>;
@@ -775,7 +775,7 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
         a.xcd_remap = xcd_forced ? atoi(xcd_env) : nb < 64 ? 0 : nb <= ncu ? 1 : 2;
     };
     auto launch = [&]() {
-        hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
+        hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO, RST>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
     };
     if (getenv("MG3D_SWEEP_BALANCED") && getenv("MG3D_SWEEP_BALANCED")[0] == '1') {
         /* experiment: equal shares of the linearised (tile column, plane) space, one block per CU, no lock-step */
@@ -1024,8 +1024,14 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
         return dispatch<4, 1>(a, env_cfg({6, 4, 2}), max_partials, s);
     if (S == 4 && !residual)
         return dispatch<4, 0>(a, env_cfg(small ? SweepCfg{2, 8, 2} : SweepCfg{4, 8, 1}), max_partials, s);
-    if (S == 2 && residual)
-        return dispatch<2, 1>(a, env_cfg({4, 8, 1}), max_partials, s);
+    if (S == 2 && residual) {
+        /* the norm alone (the top level's second post-smoothing launch): a shape without the code that assembles r */
+        const SweepCfg c = env_cfg({4, 8, 1});
+        if (!r && c.rj == 4 && c.nw == 8 && (c.pf == 1 || c.pf == 2) && !getenv("MG3D_NO_NORM_ONLY"))
+            return c.pf == 1 ? launch_sweep<2, 1, 4, 8, 1, false, false>(a, max_partials, s)
+                             : launch_sweep<2, 1, 4, 8, 2, false, false>(a, max_partials, s);
+        return dispatch<2, 1>(a, c, max_partials, s);
+    }
     if (S == 2 && !residual)
         return dispatch<2, 0>(a, env_cfg(small ? SweepCfg{2, 8, 4} : SweepCfg{4, 8, 1}), max_partials, s);
     if (S == 0 && residual)
