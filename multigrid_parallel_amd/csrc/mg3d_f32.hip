@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) jacobi32_kernel(Geom g, const float *__re
  * of a second pass over HBM).  Input and sweep-1 planes are double-buffered in LDS: one barrier per plane. */
 __device__ __forceinline__ float4 jacobi_pt4(float4 below, float4 above, float4 jm, float4 jp, float left, float4 here,
                                              float right, float4 dd, float hSq, float sixth, float omega, bool upd_plane_row,
-                                             int k0, int nk)
+                                             const bool (&kin)[4] /* column k0 + c is an interior column */)
 {
     const float hv[6] = {left, here.x, here.y, here.z, here.w, right};
     const float bl[4] = {below.x, below.y, below.z, below.w}, ab[4] = {above.x, above.y, above.z, above.w};
@@ -143,10 +143,10 @@ __device__ __forceinline__ float4 jacobi_pt4(float4 below, float4 above, float4 
     float o[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        const int k = k0 + c;
         const float s = sum6(bl[c], ab[c], jmv[c], jpv[c], hv[c], hv[c + 2]) - hSq * dv[c];
         const float gs = sixth * s;
-        o[c] = (upd_plane_row && k >= 1 && k <= nk - 2) ? hv[c + 1] + omega * (gs - hv[c + 1]) : hv[c + 1];
+        /* `&`: a select on (wave-uniform flag AND loop-invariant lane mask), not a branch per component */
+        o[c] = (upd_plane_row & kin[c]) ? hv[c + 1] + omega * (gs - hv[c + 1]) : hv[c + 1];
     }
     return make_float4(o[0], o[1], o[2], o[3]);
 }
@@ -186,13 +186,22 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
     __shared__ float4 s1b[J2_ROWS][64];
     __shared__ float4 s2b[NORM ? J2_ROWS : 1][NORM ? 64 : 1];
     __shared__ double red[16];
-    const int lane = threadIdx.x, r = threadIdx.y;
+    /* a wave is one row of the tile (blockDim.x = 64): the row index through readfirstlane, so that everything derived
+     * from it (row flags, the j parity of the prolongation) is a scalar and not a 64-bit lane mask (+0.7 %) */
+    const int lane = threadIdx.x, r = __builtin_amdgcn_readfirstlane(threadIdx.y);
     const int j = (int)blockIdx.y * OUT_ROWS - R0 + r;
     const int k0 = (int)blockIdx.x * J2_OUT_COLS - 4 + 4 * lane;
     const int i0 = blockIdx.z * chunk, i1 = min(i0 + chunk, g.ni);
     const bool in_dom = j >= 0 && j < g.nj && k0 >= 0 && k0 < g.nk; /* pitch covers a partial last vector */
     const bool row_upd = j >= 1 && j <= g.nj - 2;
     const bool own = in_dom && r >= R0 && r < R0 + OUT_ROWS && lane >= 1 && lane <= 62;
+    /* loop invariants of the plane loop, kept as scalars / lane masks: the planes that may be updated (plane_upd), the
+     * interior columns of this lane's four, the columns that enter the norm.  The scalar unit is shared by the CU's
+     * 32 waves of this kernel: per-plane tests re-evaluated in every step were a third of a step's time. */
+    const int pu_lo = max(1, 1 - g.ig0), pu_hi = min(g.ni - 2, g.N - 2 - g.ig0);
+    const bool kin[4] = {k0 >= 1 && k0 <= g.nk - 2, k0 + 1 >= 1 && k0 + 1 <= g.nk - 2, k0 + 2 >= 1 && k0 + 2 <= g.nk - 2,
+                         k0 + 3 >= 1 && k0 + 3 <= g.nk - 2};
+    const bool kacc[4] = {own && kin[0], own && kin[1], own && kin[2], own && kin[3]};
     const long long col = (long long)g.pitch * j + k0;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load = [&](const float *base, int i) { return (in_dom && i >= 0 && i < g.ni) ? ld4(base + g.plane * i + col) : zero; };
@@ -205,14 +214,23 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
     const int jt0 = (int)blockIdx.y * OUT_ROWS - R0, kt0 = (int)blockIdx.x * J2_OUT_COLS - 4;
     const int jcb = (jt0 - (jt0 & 1)) / 2, kcb = kt0 / 2; /* floor: jt0 may be odd and negative, kt0 is a multiple of 4 */
     auto slot_of = [](int c) { return ((c % 3) + 3) % 3; };
-    auto coarse_fetch = [&](int c, float(&buf)[2]) {
+    /* the two staged values of this thread: in-plane offset and validity are loop invariants (lane masks / registers),
+     * only the coarse plane index changes from fetch to fetch */
+    bool cf_ok[2];
+    long long cf_off[2];
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int idx = tid + t * 1024, row = idx / CP_COLS, cc = idx - row * CP_COLS;
-            const int jc = jcb + row, kc = kcb + cc;
-            const bool ok = idx < CP_ROWS * CP_COLS && c >= 0 && c < gc.ni && jc >= 0 && jc < gc.nj && kc >= 0 && kc < gc.nk;
-            buf[t] = ok ? ec[gc.plane * c + (long long)gc.pitch * jc + kc] : 0.f;
-        }
+    for (int t = 0; t < 2; t++) {
+        const int idx = tid + t * 1024, row = idx / CP_COLS, cc = idx - row * CP_COLS;
+        const int jc = jcb + row, kc = kcb + cc;
+        cf_ok[t] = PRO && idx < CP_ROWS * CP_COLS && jc >= 0 && jc < gc.nj && kc >= 0 && kc < gc.nk;
+        cf_off[t] = (long long)gc.pitch * jc + kc;
+    }
+    auto coarse_fetch = [&](int c, float(&buf)[2]) {
+        const bool cin = (c >= 0) & (c < gc.ni); /* wave-uniform */
+        const long long pc = gc.plane * c;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+            buf[t] = (cin & cf_ok[t]) ? ec[pc + cf_off[t]] : 0.f;
     };
     auto coarse_put = [&](int c, const float(&buf)[2]) {
         const int sl = slot_of(c);
@@ -240,26 +258,35 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
                         E0[rr][cc] = cpl[s0][lr + rr][lc + cc];
                         E1[rr][cc] = cpl[s1][lr + rr][lc + cc];
                     }
+                /* one branch on the plane's (i, j) parity class, then the four components straight-line: k even takes
+                 * the parents of column cc = c/2, k odd those of cc and cc + 1, each in the reference's order */
                 float t[4];
+                if (!oi && !oj) {
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int cc = c >> 1;
-                    if (!(c & 1)) { /* k even */
-                        if (!oi && !oj)
-                            t[c] = E0[0][cc];
-                        else if (!oi)
-                            t[c] = (E0[0][cc] + E0[1][cc]) * 0.5f;
-                        else if (!oj)
-                            t[c] = (E0[0][cc] + E1[0][cc]) * 0.5f;
-                        else
+                    for (int c = 0; c < 4; c++) {
+                        const int cc = c >> 1;
+                        t[c] = !(c & 1) ? E0[0][cc] : (E0[0][cc] + E0[0][cc + 1]) * 0.5f;
+                    }
+                } else if (!oi) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int cc = c >> 1;
+                        t[c] = !(c & 1) ? (E0[0][cc] + E0[1][cc]) * 0.5f
+                                        : (((E0[0][cc] + E0[1][cc]) + E0[0][cc + 1]) + E0[1][cc + 1]) * 0.25f;
+                    }
+                } else if (!oj) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int cc = c >> 1;
+                        t[c] = !(c & 1) ? (E0[0][cc] + E1[0][cc]) * 0.5f
+                                        : (((E0[0][cc] + E1[0][cc]) + E0[0][cc + 1]) + E1[0][cc + 1]) * 0.25f;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int cc = c >> 1;
+                        if (!(c & 1)) {
                             t[c] = (((E0[0][cc] + E0[1][cc]) + E1[0][cc]) + E1[1][cc]) * 0.25f;
-                    } else { /* k odd */
-                        if (!oi && !oj) {
-                            t[c] = (E0[0][cc] + E0[0][cc + 1]) * 0.5f;
-                        } else if (!oi) {
-                            t[c] = (((E0[0][cc] + E0[1][cc]) + E0[0][cc + 1]) + E0[1][cc + 1]) * 0.25f;
-                        } else if (!oj) {
-                            t[c] = (((E0[0][cc] + E1[0][cc]) + E0[0][cc + 1]) + E1[0][cc + 1]) * 0.25f;
                         } else {
                             float x = E0[0][cc] + E0[0][cc + 1];
                             x = x + E0[1][cc];
@@ -331,7 +358,7 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
             const float left = __shfl_up(in_c.w, 1, 64), right = __shfl_down(in_c.x, 1, 64);
             const int q = a - 1;
             s_new = jacobi_pt4(in_m, in_p, ijm, ijp, left, in_c, right, d1, hSq, sixth, omega,
-                               row_upd && plane_upd(g, q), k0, g.nk);
+                               row_upd & (q >= pu_lo) & (q <= pu_hi), kin);
         }
         s1b[r][lane] = s_new;
         /* sweep 2 of plane a-2 */
@@ -340,28 +367,28 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
             const int q = a - 2;
             const float left = __shfl_up(s_c.w, 1, 64), right = __shfl_down(s_c.x, 1, 64);
             o = jacobi_pt4(s_m, s_new, sjm, sjp, left, s_c, right, d2, hSq, sixth, omega,
-                           row_upd && plane_upd(g, q), k0, g.nk);
-            if (own && q >= i0 && q < i1)
-                st4_stream(vout + g.plane * q + col, o);
+                           row_upd & (q >= pu_lo) & (q <= pu_hi), kin);
+            if ((q >= i0) & (q < i1)) /* wave-uniform */
+                if (own)
+                    st4_stream(vout + g.plane * q + col, o);
         }
         if constexpr (NORM) {
             s2b[r][lane] = o;
             /* residual of plane a-3 (mg_3d.h:819-821) */
             const int q = a - 3;
             const float left = __shfl_up(o_c.w, 1, 64), right = __shfl_down(o_c.x, 1, 64);
-            if (own && row_upd && q >= i0 && q < i1 && plane_upd(g, q) && q >= acc_lo && q < acc_hi) {
+            /* wave-uniform: this row and plane enter the norm; which lanes / columns do is a loop-invariant mask, and
+             * adding +0 leaves a sum of squares unchanged -- a select per component instead of a branch */
+            if (row_upd & (q >= i0) & (q < i1) & (q >= pu_lo) & (q <= pu_hi) & (q >= acc_lo) & (q < acc_hi)) {
                 const float hv[6] = {left, o_c.x, o_c.y, o_c.z, o_c.w, right};
                 const float bl[4] = {o_m.x, o_m.y, o_m.z, o_m.w}, ab[4] = {o.x, o.y, o.z, o.w};
                 const float jmv[4] = {ojm.x, ojm.y, ojm.z, ojm.w}, jpv[4] = {ojp.x, ojp.y, ojp.z, ojp.w};
                 const float dv[4] = {d3.x, d3.y, d3.z, d3.w};
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const int k = k0 + c;
-                    if (k >= 1 && k <= g.nk - 2) {
-                        const float ssum = sum6(bl[c], ab[c], jmv[c], jpv[c], hv[c], hv[c + 2]) - 6 * hv[c + 1];
-                        const float diff = dv[c] - invHsq * ssum;
-                        acc += (double)diff * (double)diff;
-                    }
+                    const float ssum = sum6(bl[c], ab[c], jmv[c], jpv[c], hv[c], hv[c + 2]) - 6 * hv[c + 1];
+                    const float diff = dv[c] - invHsq * ssum;
+                    acc += kacc[c] ? (double)diff * (double)diff : 0.;
                 }
             }
             o_m = o_c;
