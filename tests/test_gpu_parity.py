@@ -636,3 +636,29 @@ def test_small_level_policy_changes_no_bit(monkeypatch, c, L, nu, small, legs):
         assert np.array_equal(a, b)
     want_norms, want_u, _, _ = O.run_problem(c, L, nu, 3)
     assert np.array_equal(res[0][1][-1], want_u)
+
+
+def test_two_host_threads_solve_concurrently():
+    """Two contexts driven from two host threads at once (ctypes releases the GIL): the sweep launcher's first-use
+    measurement and its remembered choices are process-wide and mutex-protected; both solves give the oracle's bits."""
+    import threading
+
+    c, L, nu = 9, 5, 2  # 129^3: the levels large enough for the measurement to run
+    want_norms, want_u, _, _ = O.run_problem(c, L, nu, 3)
+    out = {}
+
+    def work(tag):
+        with M.Solver(c, L, nu) as s:
+            s.setup_test_problem()
+            n = s.vcycles(3)
+            out[tag] = (n, s.download(MG3D_U, L - 1))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+        assert not t.is_alive()
+    for t in range(2):
+        assert np.array_equal(out[t][1], want_u)
+        np.testing.assert_allclose(out[t][0], want_norms, rtol=norm_rtol((c - 1) * (1 << (L - 1)) + 1))
