@@ -797,7 +797,9 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
      * MG3D_SWEEP_TUNE=0 keeps the model's choice. */
     const char *tune_env = getenv("MG3D_SWEEP_TUNE");
     const bool tune_on = !(tune_env && tune_env[0] == '0');
-    if (!forced && tune_on && T * nout >= 1024) {
+    /* not for the launches that form the norm: its value depends (in the last bits) on how the points are grouped
+     * into per-block partial sums, and a timing-dependent choice would make it differ from run to run */
+    if (!forced && tune_on && !a.partials && T * nout >= 1024) {
         struct Key {
             int v[12];
             bool operator<(const Key &o) const { return memcmp(v, o.v, sizeof v) < 0; }

@@ -598,7 +598,7 @@ def test_measured_chunk_length_changes_no_bit(monkeypatch):
     the cost model's choice; MG3D_SWEEP_CI: a fixed one).  Chunking is a work distribution only: same grid values (the norm is a sum of per-block partial sums).""" 
     c, L, nu = 9, 5, 2  # 129^3: large enough for the measurement to run
     res = []
-    for env in ({"MG3D_SWEEP_TUNE": "0"}, {}, {"MG3D_SWEEP_CI": "5"}, {"MG3D_SWEEP_TAIL": "1", "MG3D_SWEEP_TUNE": "0"}):
+    for env in ({"MG3D_SWEEP_TUNE": "0"}, {}, {"MG3D_SWEEP_CI": "5"}, {"MG3D_SWEEP_TAIL": "1", "MG3D_SWEEP_TUNE": "0"}, {}):
         for k in ("MG3D_SWEEP_TUNE", "MG3D_SWEEP_CI", "MG3D_SWEEP_TAIL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -610,6 +610,8 @@ def test_measured_chunk_length_changes_no_bit(monkeypatch):
     for r in res[1:]:
         assert np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
         np.testing.assert_allclose(r[0], res[0][0], rtol=1e-13)  # one partial sum per block: the grouping differs
+    # launches that form a norm are not measured: with or without the measurement the norms are the same bits
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[1][0], res[4][0])
     want_norms, want_u, _, _ = O.run_problem(c, L, nu, 3)
     assert np.array_equal(res[0][1], want_u)
 
