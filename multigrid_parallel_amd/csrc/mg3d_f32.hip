@@ -514,7 +514,10 @@ __global__ void __launch_bounds__(1024) residual_restrict32_kernel(Geom g, const
                                                                    float *__restrict__ dc, int cchunk, int c_lo, int c_hi)
 {
     __shared__ float4 inp[2][J2_ROWS][64];
-    __shared__ float rb[2][J2_ROWS][256];
+    /* r of the tile's plane, even and odd columns apart: the restriction reads tile columns 3+2k, 4+2k, 5+2k for
+     * consecutive coarse points k -- stride 2 in one array (two-way bank conflicts on each of the nine reads: half
+     * of the kernel's LDS cycles), stride 1 in [parity][column / 2] */
+    __shared__ float rb[2][J2_ROWS][2][128];
     const int lane = threadIdx.x, r = threadIdx.y, tid = r * 64 + lane;
     const int jt0 = (int)blockIdx.y * J2_OUT_ROWS - 2, kt0 = (int)blockIdx.x * J2_OUT_COLS - 4;
     const int j = jt0 + r, k0 = kt0 + 4 * lane;
@@ -559,7 +562,8 @@ __global__ void __launch_bounds__(1024) residual_restrict32_kernel(Geom g, const
                 /* r is zero where the reference never writes it (boundary points, mg_3d.h:824-825) */
                 df[c] = (row_int && k >= 1 && k <= g.nk - 2) ? dv[c] - invHsq * s : 0.f;
             }
-            *reinterpret_cast<float4 *>(&rb[pb][r][4 * lane]) = make_float4(df[0], df[1], df[2], df[3]);
+            *reinterpret_cast<float2 *>(&rb[pb][r][0][2 * lane]) = make_float2(df[0], df[2]); /* columns 4 lane, 4 lane + 2 */
+            *reinterpret_cast<float2 *>(&rb[pb][r][1][2 * lane]) = make_float2(df[1], df[3]); /* columns 4 lane + 1, + 3 */
         }
         __syncthreads();
         if (cown) {
@@ -572,7 +576,9 @@ __global__ void __launch_bounds__(1024) residual_restrict32_kernel(Geom g, const
 #pragma unroll
                 for (int tk = 0; tk < 3; tk++) {
                     const float w = (wi * (tj == 1 ? 0.5f : 0.25f)) * (tk == 1 ? 0.5f : 0.25f);
-                    p9[tj * 3 + tk] = rb[pb][fr - 1 + tj][fc - 1 + tk] * w;
+                    /* tile column fc - 1 + tk, fc even: tk = 1 is even column fc, tk = 0 / 2 the odd ones beside it */
+                    p9[tj * 3 + tk] = (tk == 1 ? rb[pb][fr - 1 + tj][0][fc >> 1]
+                                               : rb[pb][fr - 1 + tj][1][(fc >> 1) - 1 + (tk >> 1)]) * w;
                 }
             if (qg & 1) {
                 /* completes coarse plane (qg-1)/2, starts coarse plane (qg+1)/2 */
