@@ -243,8 +243,7 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
     };
     /* v_in(plane i) = u + P(ec): the staged planes cover coarse_lo(i) and, for odd i, the one above.  Parity and
      * parents follow the GLOBAL plane index ig0 + i; cl is the local index of the lower coarse parent plane. */
-    auto load_in = [&](int i) {
-        float4 v = load(vin, i);
+    auto pro_apply = [&](float4 v, int i) { /* v = plane i of vin as loaded */
         if constexpr (PRO) {
             if (in_dom && i >= 0 && i < g.ni) {
                 const int oi = (g.ig0 + i) & 1, oj = j & 1;
@@ -320,15 +319,30 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
         have_hi = lo + 2;
         __syncthreads();
     }
+    auto load_in = [&](int i) { return pro_apply(load(vin, i), i); };
     float4 in_m = load_in(a0 - 2), in_c = load_in(a0 - 1), s_m = zero, s_c = zero, d2 = zero, d3 = zero;
     float4 o_m = zero, o_c = zero;
     double acc = 0.;
     s1b[r][lane] = zero;
     if constexpr (NORM)
         s2b[r][lane] = zero;
+    /* The NORM / PRO variants need 73-103 VGPRs: one block per CU, nobody to hide a load behind.  They request the next
+     * step's planes a step ahead (8 more registers, same occupancy); the plain pair runs two blocks per CU at 63 VGPRs
+     * and must not grow. */
+    constexpr bool PREF = NORM || PRO;
+    float4 raw_next = PREF ? load(vin, a0) : zero, d_next = PREF ? load(d, a0 - 1) : zero;
     for (int a = a0; a <= a1; a++) {
-        const float4 in_p = load_in(a);
-        const float4 d1 = load(d, a - 1);
+        float4 raw, d1;
+        if constexpr (PREF) {
+            raw = raw_next;
+            d1 = d_next;
+            raw_next = load(vin, a + 1);
+            d_next = load(d, a);
+        } else {
+            raw = load(vin, a);
+            d1 = load(d, a - 1);
+        }
+        const float4 in_p = pro_apply(raw, a);
         float cbuf[2];
         bool stage_new = false;
         if constexpr (PRO) { /* plane a+1 (global G) needs coarse planes up to ceil(G/2) */
