@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (run on the GPU box): many (coarse points, levels, sweeps) combinations, a few cycles each,
-every grid value of the finest level compared with the oracle bit for bit.  Usage: random_parity.py [count seed]"""
+every grid value of the finest level compared with the oracle bit for bit.  Usage: python tests/random_parity.py [count seed]  (a checker script: it lives under tests/ because it calls the oracle)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import multigrid_parallel_amd as M
 from multigrid_parallel_amd.binding import MG3D_U, MG3D_D
