@@ -1,7 +1,7 @@
 #!/bin/bash
 # AddressSanitizer + UBSan over the CPU-side C code (GPU sanitizers are not available on the pool): the checker
 # (oracle/*.c: fp64, fp32 and mixed-boundary cycles) and the product's host side (csrc/mg3d_host.c: coarse operators,
-# LU factorisation, boundary fill, edge cosmetics).  Usage: tools/sanitize_cpu.sh   (no GPU needed)
+# LU factorisation, boundary fill, edge cosmetics).  Usage: tests/sanitize_cpu.sh   (no GPU needed; under tests/ because it builds and runs the oracle)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); T=$(mktemp -d)
 SAN="-O1 -g -ffp-contract=off -fPIC -std=gnu99 -fsanitize=address,undefined -fno-omit-frame-pointer -shared"
