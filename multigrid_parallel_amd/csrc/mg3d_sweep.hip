@@ -123,15 +123,17 @@ __device__ __forceinline__ double lane_from_right(double x) /* lane l receives l
 }
 
 /* Cache policy of the streams (compile-time MG3D_NT bits: 1 = u loads, 4 = d loads, 2 = u stores non-temporal, 8 = in
- * the pure residual launches (S = 0) the loads of the rows no other tile column reads; default 2 + 8).
+ * the pure residual launches (S = 0) the loads of the rows no other tile column reads; default 2).
  * The output is not read again before the next launch, a gigabyte later: written non-temporally it does not push the
  * halo rows the neighbouring tile columns are about to re-read out of L2 / the Infinity Cache (513^3: 265 -> 274
  * V-cycles/s).  Non-temporal LOADS lose exactly those halo re-reads (231 V-cycles/s); write-through stores
  * (`sc1`, `sc0 sc1`, `sc1 nt` by inline asm) measured 258-263.  Loading only the read-once rows non-temporally
- * helps the residual + restriction launch (0.64 -> 0.59 ms) and hurts the smoothing launches (0.72 -> 0.88). */
+ * helped the residual + restriction launch while it kept two planes in flight (0.64 -> 0.59 ms) and hurt the smoothing
+ * launches (0.72 -> 0.88); with one plane in flight it no longer does (513^3: 0.566 against 0.554 ms without, 257^3:
+ * 0.088 against 0.079), so bit 8 is off again. */
 typedef double v2d __attribute__((ext_vector_type(2)));
 #ifndef MG3D_NT
-#define MG3D_NT 10
+#define MG3D_NT 2
 #endif
 template <int BIT> __device__ __forceinline__ double2 ld_stream(const double *p)
 {
