@@ -42,7 +42,11 @@
 #include "timing_info.h"
 #include "mg3d.h"
 
-/* ---- the reference's global solver state (mg_3d.h:19-28) ---------------------------- */
+/* ---- the reference's global solver state (mg_3d.h:19-28) ----------------------------
+ * The reference defines these with EXTERNAL linkage inside its header, which only works for a program that is a
+ * single translation unit (a second TU including mg_3d.h would fail to link).  Here they are `static`: every
+ * including TU gets its own solver instance.  The reference's drivers are single-TU programs, so nothing observable
+ * changes; a multi-TU program must keep all Solver* calls in one TU. */
 static TimingInfo **tInfo = NULL;
 static int coarseGridNum;
 static int finestOneSideNum;
@@ -55,7 +59,9 @@ static double spacing;
 /* ---- state of this implementation ---------------------------------------------------- */
 static mg3d_ctx *mg3d_solver_ctx_ = NULL;
 static int mg3d_host_newer_ = 1;   /* host finest u/d written since the last upload */
+static int mg3d_rhs_newer_ = 0;    /* host finest d alone written since the last upload (SolverMarkHostDirty) */
 static int mg3d_device_newer_ = 0; /* device u newer than the host mirror */
+static int mg3d_fmg_done_ = 0;     /* MG3D_USE_FMG=1: the F-cycle start has run */
 static double mg3d_team_norm_ = 0.;
 static int mg3d_pinned_top_ = 0;   /* finest u and d come from mg3d_host_alloc */
 
@@ -211,8 +217,15 @@ static inline double mg3d_vcycle8_(double **lu_, double **lf_, double **lres_, i
  * into the arrays SolverGetDetails handed out, and -- because the caller owns those arrays and may write
  * grid[] / rhs[] through the raw pointers at any time after such a call (the reference sees such writes,
  * mg_3d.h:278-279) -- the next SolverLinSolve uploads them again.  Writes between two consecutive
- * SolverLinSolve calls with no other Solver* call in between are not visible to a call counter: announce
- * them with SolverMarkHostDirty(), or run with MG3D_SYNC_EVERY_CYCLE=1 (download + upload around every cycle). */
+ * SolverLinSolve calls with no other Solver* call in between are not visible to a call counter; two calls
+ * that are not in the reference cover them (or run with MG3D_SYNC_EVERY_CYCLE=1: download + upload around
+ * every cycle):
+ *   SolverSyncHost()       call BEFORE reading or writing grid[]: brings the device iterate into grid[] and hands
+ *                          both arrays back to the caller (everything is uploaded again by the next SolverLinSolve);
+ *   SolverMarkHostDirty()  call AFTER writing rhs[]: a flag only, it never copies anything back, so writes made
+ *                          before it are never overwritten.  rhs[] is uploaded by the next SolverLinSolve; grid[] too
+ *                          if the host copy is current (no solve since the last hand-back).  Writes to grid[] made
+ *                          while the device iterate is newer than grid[] cannot be merged: SolverSyncHost() first. */
 static inline void mg3d_pull_(void)
 {
     if (mg3d_solver_ctx_ && mg3d_device_newer_) {
@@ -222,10 +235,14 @@ static inline void mg3d_pull_(void)
     mg3d_host_newer_ = 1;
 }
 
-/* not in the reference: tells the facade that grid[] / rhs[] were written between two SolverLinSolve calls */
+static inline void SolverSyncHost(void) { mg3d_pull_(); }
+
 static inline void SolverMarkHostDirty(void)
 {
-    mg3d_pull_();
+    if (mg3d_device_newer_)
+        mg3d_rhs_newer_ = 1; /* the device iterate stays the authoritative u */
+    else
+        mg3d_host_newer_ = 1;
 }
 
 static inline void SolverInitialize(int argc, char **argv)
@@ -269,7 +286,9 @@ static inline void SolverInitialize(int argc, char **argv)
               "SolverInitialize");
     mg3d_die_(mg3d_timing_enable(mg3d_solver_ctx_, 1), "SolverInitialize");
     mg3d_host_newer_ = 1;
+    mg3d_rhs_newer_ = 0;
     mg3d_device_newer_ = 0;
+    mg3d_fmg_done_ = 0;
 }
 
 static inline int SolverGetDetails(double **grid, double **rhs, double *h)
@@ -294,32 +313,6 @@ static inline void SolverSetupBoundaryConditions(void)
     mg3d_host_newer_ = 1;
 }
 
-/* One V-cycle.  Entered by every thread of the caller's team (test_mg_3d.c:37-45); the
- * squares of the return values are summed by the caller, so the master returns the norm
- * and everybody else 0.  The two barriers keep the team together around the GPU work. */
-static inline double SolverLinSolve(void)
-{
-    double ret = 0.;
-#pragma omp barrier
-#pragma omp master
-    {
-        const int fin = numLevels - 1;
-        if (mg3d_host_newer_) {
-            mg3d_die_(mg3d_upload(mg3d_solver_ctx_, MG3D_U, fin, u[fin]), "SolverLinSolve");
-            mg3d_die_(mg3d_upload(mg3d_solver_ctx_, MG3D_D, fin, d[fin]), "SolverLinSolve");
-            mg3d_host_newer_ = 0;
-        }
-        mg3d_die_(mg3d_vcycle(mg3d_solver_ctx_, fin, &mg3d_team_norm_), "SolverLinSolve");
-        mg3d_device_newer_ = 1;
-        const char *eager = getenv("MG3D_SYNC_EVERY_CYCLE");
-        if (eager && eager[0] == '1')
-            mg3d_pull_();
-        ret = mg3d_team_norm_;
-    }
-#pragma omp barrier
-    return ret;
-}
-
 /* SolverFMGInitialize: live in mg_dirichlet_analytic.c:771-806, commented out in mg_3d.h:1364-1404 */
 static inline void SolverFMGInitialize(void)
 {
@@ -330,10 +323,56 @@ static inline void SolverFMGInitialize(void)
             mg3d_die_(mg3d_upload(mg3d_solver_ctx_, MG3D_D, l, d[l]), "SolverFMGInitialize");
         }
         mg3d_host_newer_ = 0;
+        mg3d_rhs_newer_ = 0;
+    }
+    if (mg3d_rhs_newer_) {
+        mg3d_die_(mg3d_upload(mg3d_solver_ctx_, MG3D_D, fin, d[fin]), "SolverFMGInitialize");
+        mg3d_rhs_newer_ = 0;
     }
     mg3d_die_(mg3d_fmg_initialize(mg3d_solver_ctx_), "SolverFMGInitialize");
     mg3d_device_newer_ = 1;
-    (void)fin;
+}
+
+/* One V-cycle.  Entered by every thread of the caller's team (test_mg_3d.c:37-45); the
+ * squares of the return values are summed by the caller, so the master returns the norm
+ * and everybody else 0.  The two barriers keep the team together around the GPU work. */
+static inline double SolverLinSolve(void)
+{
+    double ret = 0.;
+#pragma omp barrier
+#pragma omp master
+    {
+        const int fin = numLevels - 1;
+        /* MG3D_USE_FMG=1: what the fifth argument `useFMG` of mg_dirichlet_analytic.c:70-80 selects -- the F-cycle
+         * start of :984-988 once, in front of the first cycle (test_mg_3d.c has no such argument and stays unchanged).  It uploads every
+         * level of the host hierarchies itself */
+        if (!mg3d_fmg_done_) {
+            const char *fmg = getenv("MG3D_USE_FMG");
+            mg3d_fmg_done_ = 1;
+            if (fmg && fmg[0] == '1') {
+                printf("Doing FMG Initialization...."); /* mg_dirichlet_analytic.c:986-988 */
+                SolverFMGInitialize();
+                printf("done\n");
+            }
+        }
+        if (mg3d_host_newer_) {
+            mg3d_die_(mg3d_upload(mg3d_solver_ctx_, MG3D_U, fin, u[fin]), "SolverLinSolve");
+            mg3d_die_(mg3d_upload(mg3d_solver_ctx_, MG3D_D, fin, d[fin]), "SolverLinSolve");
+            mg3d_host_newer_ = 0;
+            mg3d_rhs_newer_ = 0;
+        } else if (mg3d_rhs_newer_) {
+            mg3d_die_(mg3d_upload(mg3d_solver_ctx_, MG3D_D, fin, d[fin]), "SolverLinSolve");
+            mg3d_rhs_newer_ = 0;
+        }
+        mg3d_die_(mg3d_vcycle(mg3d_solver_ctx_, fin, &mg3d_team_norm_), "SolverLinSolve");
+        mg3d_device_newer_ = 1;
+        const char *eager = getenv("MG3D_SYNC_EVERY_CYCLE");
+        if (eager && eager[0] == '1')
+            mg3d_pull_();
+        ret = mg3d_team_norm_;
+    }
+#pragma omp barrier
+    return ret;
 }
 
 static inline void SolverSmoothenEdgeValues(void)

@@ -107,23 +107,61 @@ static void resolve_timers(mg3d_ctx *ctx)
     ctx->pending.clear();
 }
 
-/* scoped event pair: a stage of the reference's timing table, or (kernel = true) one kernel launch */
+/* scoped event pair: a stage of the reference's timing table, or (kernel = true) one kernel launch.
+ * embed = true (kernel scopes that wrap exactly ONE fused-sweep launch): no marker packets; the pair is published for
+ * launch_sweep, which binds it to the dispatch itself (mg3d_internal.h, LaunchEvents).  timing: 1 every level, 2 the
+ * finest level, 3 the finest level's kernel scopes only (what bench.py's roofline needs, at the least cost). */
+static bool timing_embed()
+{
+    static const bool off = getenv("MG3D_TIMING_EMBED") && getenv("MG3D_TIMING_EMBED")[0] == '0';
+    return !off;
+}
+
 struct StageScope {
     mg3d_ctx *ctx;
     mg3d_ctx::Pending p;
-    bool on;
-    StageScope(mg3d_ctx *c, int l, int s, bool kernel = false) : ctx(c)
+    bool on, embedded;
+    LaunchEvents le, *prev;
+    StageScope(mg3d_ctx *c, int l, int s, bool kernel = false, bool embed = false) : ctx(c), embedded(false), prev(nullptr)
     {
         p.slot = kernel ? c->L * MG3D_NUM_STAGES + l * MG3D_NUM_KERNELS + s : l * MG3D_NUM_STAGES + s;
         p.a = p.b = nullptr;
-        on = ctx->timing == 1 || (ctx->timing == 2 && l == ctx->L - 1);
-        if (on && (p.a = take_event(ctx)))
+        on = ctx->timing == 1 || (ctx->timing == 2 && l == ctx->L - 1) || (ctx->timing == 3 && kernel && l == ctx->L - 1);
+        if (!on)
+            return;
+        if (kernel && embed && timing_embed()) {
+            p.a = take_event(ctx);
+            p.b = take_event(ctx);
+            if (p.a && p.b) {
+                embedded = true;
+                le = LaunchEvents{p.a, p.b, false};
+                prev = mg3d_launch_events;
+                mg3d_launch_events = &le;
+                return;
+            }
+            if (p.a)
+                ctx->event_pool.push_back(p.a);
+            if (p.b)
+                ctx->event_pool.push_back(p.b);
+            p.a = p.b = nullptr;
+        }
+        if ((p.a = take_event(ctx)))
             (void)hipEventRecord(p.a, ctx->stream);
     }
     ~StageScope()
     {
         if (!on)
             return;
+        if (embedded) {
+            mg3d_launch_events = prev;
+            if (le.used) {
+                ctx->pending.push_back(p);
+            } else { /* nothing was launched inside the scope */
+                ctx->event_pool.push_back(p.a);
+                ctx->event_pool.push_back(p.b);
+            }
+            return;
+        }
         if ((p.b = take_event(ctx)))
             (void)hipEventRecord(p.b, ctx->stream);
         ctx->pending.push_back(p);
@@ -584,7 +622,7 @@ static int enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters
             int np;
             {
                 StageScope kt(ctx, level, S == 4 ? MG3D_K_SWEEP4 : S == 2 ? (res ? MG3D_K_SWEEP2_RES : MG3D_K_SWEEP2)
-                                                                          : MG3D_K_RESIDUAL, true);
+                                                                          : MG3D_K_RESIDUAL, true, /* embed: one launch */ true);
                 np = k_sweep(l.g, (zero_in && passes == 2 * iters) ? nullptr : l.f[MG3D_U], l.f[MG3D_D], l.alt,
                              (res && want_res == 2 && !rst) ? l.f[MG3D_R] : nullptr,
                              (res && need_norm) ? ctx->partials : nullptr,
@@ -917,7 +955,7 @@ extern "C" int mg3d_timing_enable(mg3d_ctx *ctx, int on)
 {
     if (!ctx)
         return fail(MG3D_ERR_ARG, "mg3d_timing_enable: NULL context");
-    ctx->timing = (on == 1 || on == 2) ? on : 0;
+    ctx->timing = (on >= 1 && on <= 3) ? on : 0;
     return MG3D_OK;
 }
 

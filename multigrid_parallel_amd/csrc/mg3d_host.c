@@ -100,19 +100,40 @@ void mg3d_es_coarse_matrix(double *A, int N, double h, const mg3d_es_params *p)
 
 /* convertToLU_InPlace, gauss_elim.h:9-29: Doolittle, unit-lower, no pivoting,
  * row-major in place.  The multiplier z = a[k][i] / a[i][i] is formed as
- * a[k][i] * (1/a[i][i]) exactly as :17,:22 do.  Rows whose multiplier is an
- * exact zero are skipped (a -= 0*x leaves a unchanged), as are columns past the
- * last non-zero of the pivot row: the matrix is banded (half-width N^2), which
- * turns the O(n^3) dense sweep into O(n * bw^2). */
+ * a[k][i] * (1/a[i][i]) exactly as :17,:22 do.  The matrix is banded (half-width N^2)
+ * and elimination without pivoting never fills outside the band, so only the
+ * rows and columns inside it are visited: O(n * bw^2) instead of the dense O(n^3)
+ * (c = 33: 4e10 instead of 1.5e13 operations).  What is skipped leaves every entry
+ * as the dense loop would: a row whose multiplier is an exact zero changes nothing
+ * (a -= 0*x), a zero of the pivot row likewise; the multiplier itself is stored as
+ * the signed zero (+0) * (1/a[i][i]) the dense loop writes (:21-22), inside the band
+ * by the loop below, outside it by the last pass. */
 void mg3d_lu_factor(double *a, int n)
 {
+    int bwl = 0, bwu = 0; /* populated half-bandwidths of the input */
+    for (int i = 0; i < n; i++) {
+        const double *ri = a + (long)n * i;
+        int lo = 0, hi = n - 1;
+        while (lo < i && ri[lo] == 0.)
+            lo++;
+        while (hi > i && ri[hi] == 0.)
+            hi--;
+        if (i - lo > bwl)
+            bwl = i - lo;
+        if (hi - i > bwu)
+            bwu = hi - i;
+    }
+    double *pinvs = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
     for (int i = 0; i < n - 1; i++) {
         const double *ri = a + (long)n * i;
         const double pinv = 1. / ri[i];
-        int last = n - 1; /* last non-zero column of the pivot row */
+        if (pinvs)
+            pinvs[i] = pinv;
+        int last = i + bwu < n - 1 ? i + bwu : n - 1; /* last non-zero column of the pivot row */
         while (last > i && ri[last] == 0.)
             last--;
-        for (int k = i + 1; k < n; k++) {
+        const int klast = i + bwl < n - 1 ? i + bwl : n - 1;
+        for (int k = i + 1; k <= klast; k++) {
             double *rk = a + (long)n * k;
             if (rk[i] == 0.) {
                 rk[i] = rk[i] * pinv; /* keeps the sign of zero the reference would store */
@@ -123,6 +144,15 @@ void mg3d_lu_factor(double *a, int n)
             for (int j = i + 1; j <= last; j++)
                 rk[j] -= z * ri[j];
         }
+    }
+    /* below the band: the entry is still the input's zero when the dense loop reaches it; it stores zero * pinv */
+    if (pinvs) {
+        for (int k = bwl + 1; k < n; k++) {
+            double *rk = a + (long)n * k;
+            for (int i = 0; i < k - bwl; i++)
+                rk[i] = rk[i] * pinvs[i];
+        }
+        free(pinvs);
     }
 }
 

@@ -45,6 +45,16 @@ struct LuBand {
 
 #define MG3D_MAX_PARTIALS 32768
 
+/* Launch timing without extra packets in the queue: a kernel timer scope (mg3d_ctx.hip) that wraps exactly one fused
+ * sweep launch publishes its event pair here; launch_sweep hands the pair to hipExtLaunchKernelGGL, which binds both to
+ * the dispatch itself (start/end of that kernel) instead of recording two marker packets around it -- each marker costs
+ * ~5 us of idle queue (24 of them per cycle were 0.1 ms of a 3.3 ms cycle).  MG3D_TIMING_EMBED=0: markers again. */
+struct LaunchEvents {
+    hipEvent_t a, b;
+    bool used;
+};
+extern thread_local LaunchEvents *mg3d_launch_events;
+
 /* launchers (mg3d_kernels.hip); all asynchronous on `s` */
 void k_smooth_color(const Geom &g, double *v, const double *d, double hSq, int color, hipStream_t s);
 /* writes partials (one per block) then reduces them, in a fixed order, into *sumsq_out */

@@ -84,6 +84,64 @@ void orc_lu_factor(double *a, int n)
     }
 }
 
+/* The same elimination for coarse grids whose dense O(n^3) sweep is out of reach (c = 17: n = 4913, c = 33:
+ * n = 35937, 1.5e13 operations): every operation of gauss_elim.h:9-29 that can change a value is performed, in the
+ * reference's order per entry; the ones left out have an exact zero as a factor.  Rows are described by the first
+ * non-zero column they start with (elimination without pivoting never extends a row to the left), pivot rows by
+ * their current last non-zero column.  tests/test_oracle_golden.py pins this against orc_lu_factor (byte for byte,
+ * signed zeros included) at c = 3, 5, 9 and on random banded matrices. */
+void orc_lu_factor_banded(double *a, int n)
+{
+    int *first = (int *)malloc(sizeof(int) * (size_t)n), *lastc = (int *)malloc(sizeof(int) * (size_t)n);
+    int *reach = (int *)malloc(sizeof(int) * (size_t)n); /* reach[i] = last row whose first non-zero column is <= i */
+    double *pinv = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int k = 0; k < n; k++) {
+        const double *r = a + (long)n * k;
+        int f = 0, l = n - 1;
+        while (f < k && r[f] == 0.)
+            f++;
+        while (l > k && r[l] == 0.)
+            l--;
+        first[k] = f;
+        lastc[k] = l;
+    }
+    for (int i = 0; i < n; i++)
+        reach[i] = i;
+    for (int k = 0; k < n; k++) /* rows k with first[k] <= i for all i >= first[k] */
+        if (reach[first[k]] < k)
+            reach[first[k]] = k;
+    for (int i = 1; i < n; i++)
+        if (reach[i] < reach[i - 1])
+            reach[i] = reach[i - 1];
+    for (int i = 0; i < n - 1; i++) {
+        const double *ri = a + (long)n * i;
+        const double aii_inv = 1. / ri[i]; /* :17 */
+        const int li = lastc[i], kend = reach[i];
+        pinv[i] = aii_inv;
+#pragma omp parallel for schedule(static) if (kend - i > 64)
+        for (int k = i + 1; k <= kend; k++) {
+            double *rk = a + (long)n * k;
+            const double z = rk[i] * aii_inv; /* :21 */
+            rk[i] = z;                        /* :22 */
+            for (int j = i + 1; j <= li; j++)
+                rk[j] -= z * ri[j];           /* :25 */
+            if (lastc[k] < li && z != 0.)
+                lastc[k] = li;
+        }
+    }
+    /* rows never reached by pivot i (first[k] > i): the dense loop multiplies their untouched zero by 1/a[i][i] */
+    for (int k = 1; k < n; k++) {
+        double *rk = a + (long)n * k;
+        for (int i = 0; i < k && i < n - 1; i++)
+            if (k > reach[i])
+                rk[i] = rk[i] * pinv[i];
+    }
+    free(first);
+    free(lastc);
+    free(reach);
+    free(pinv);
+}
+
 /* gauss_elim.h:31-60: forward j ascending (:39-41), backward j descending
  * from n-1 (:54-55), divide by the diagonal (:57). */
 void orc_lu_solve(const double *LU, int n, const double *b, double *x)
@@ -335,7 +393,10 @@ double orc_run_problem(int c, int L, int iters, int cycles, int coarse_h_mode, d
     const size_t n0 = (size_t)c * c * c;
     double *A = (double *)calloc(n0 * n0, sizeof(double));
     orc_coarse_matrix(A, c, coarse_h_mode ? h : h * (1 << (L - 1))); /* mg_3d.h:287 | dirichlet:40 */
-    orc_lu_factor(A, (int)n0);
+    if (c > 9) /* c = 17, 33 (admissible by mg_3d.h:163): the dense sweep needs 4e10 / 1.5e13 operations */
+        orc_lu_factor_banded(A, (int)n0);
+    else
+        orc_lu_factor(A, (int)n0);
     double init = 0.;
     if (!coarse_h_mode) {
         orc_fill_boundary(d[L - 1], N, h);           /* test_mg_3d.c:17 */

@@ -32,6 +32,8 @@ void orc_fill_boundary(double *v, int N, double h);
 void orc_coarse_matrix(double *A, int N, double h);
 /* gauss_elim.h:9-29 */
 void orc_lu_factor(double *a, int n);
+/* the same factor, skipping operations with an exact zero factor (wide coarse grids; pinned to orc_lu_factor by the tests) */
+void orc_lu_factor_banded(double *a, int n);
 /* gauss_elim.h:31-60 */
 void orc_lu_solve(const double *LU, int n, const double *b, double *x);
 

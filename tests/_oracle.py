@@ -32,6 +32,8 @@ def lib():
         L.orc_fill_boundary.argtypes = [dp, C.c_int, C.c_double]
         L.orc_coarse_matrix.argtypes = [dp, C.c_int, C.c_double]
         L.orc_lu_factor.argtypes = [dp, C.c_int]
+        L.orc_lu_factor_banded.argtypes = [dp, C.c_int]
+        L.orc_lu_factor_banded.restype = None
         L.orc_lu_solve.argtypes = [dp, C.c_int, dp, dp]
         L.orc_smooth_color.argtypes = [dp, dp, C.c_int, C.c_double, C.c_int]
         L.orc_pre_smooth.argtypes = [dp, dp, C.c_int, C.c_double, C.c_int]

@@ -1,6 +1,8 @@
 /* host_dirty.c -- "solve, inspect, change rhs and grid through the raw pointers, solve again" through the
  * drop-in facade (include/mg_3d.h).  The reference hands out raw pointers (mg_3d.h:278-279) and sees every
  * write to them; the facade re-uploads after any Solver* call that gave the arrays back to the caller.
+ * Between two consecutive SolverLinSolve calls: SolverSyncHost() BEFORE touching grid[], SolverMarkHostDirty()
+ * AFTER writing rhs[] (both orders of "write" and "announce" are exercised).
  * Prints the norms; tests/test_dropin.py replays the same sequence with the oracle. */
 #include <stdio.h>
 #include <string.h>
@@ -28,9 +30,17 @@ int main(void)
     rhs[mid - N] = -125.0;
     for (int c = 0; c < 2; c++)
         printf("C %.17g\n", SolverLinSolve());
-    SolverMarkHostDirty(); /* explicit: writes between two SolverLinSolve calls */
+    SolverSyncHost(); /* explicit hand-back BEFORE touching grid[] between two SolverLinSolve calls */
     grid[mid - 1] -= 0.25;
     printf("D %.17g\n", SolverLinSolve());
+    rhs[mid + N] = 60.0;   /* write first ... */
+    SolverMarkHostDirty(); /* ... announce afterwards: a flag only, the write above must survive it */
+    printf("E %.17g\n", SolverLinSolve());
+    SolverSyncHost();
+    grid[mid + 2] += 0.5;
+    rhs[mid + 2] = -30.0;
+    SolverMarkHostDirty(); /* after a hand-back both arrays are the caller's: nothing may be lost either */
+    printf("F %.17g\n", SolverLinSolve());
     SolverPrintTimingInfo();
     double s = 0.;
     for (int p = 0; p < N * N * N; p++)

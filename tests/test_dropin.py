@@ -168,7 +168,8 @@ def test_api_surface_driver(tmp_path):
 @pytest.mark.gpu
 def test_facade_sees_host_writes_between_solves(tmp_path):
     """tests/c/host_dirty.c: rhs[] and grid[] are changed through the raw pointers of SolverGetDetails after
-    SolverGetResidual / SolverResetTimingInfo / SolverMarkHostDirty; the following cycles must start from those
+    SolverGetResidual / SolverResetTimingInfo / SolverSyncHost and announced after the fact with SolverMarkHostDirty
+    (write-then-call order: the flag-only call must not clobber the write); the following cycles must start from those
     writes, as they do in the reference (mg_3d.h:278-279 hands out the solver's own arrays)."""
     exe = tmp_path / "host_dirty"
     subprocess.run(["gcc", "-O2", "-fopenmp", "-I" + os.path.join(ROOT, "include"), "-o", str(exe),
@@ -202,14 +203,41 @@ def test_facade_sees_host_writes_between_solves(tmp_path):
     Cc = [cyc() for _ in range(2)]
     H.u[-1][mid - 1] -= 0.25
     D = [cyc()]
+    H.d[-1][mid + N] = 60.0  # written BEFORE SolverMarkHostDirty(): a flag-only call must not overwrite it
+    E = [cyc()]
+    H.u[-1][mid + 2] += 0.5
+    H.d[-1][mid + 2] = -30.0
+    F = [cyc()]
     assert val("A") == pytest.approx(A, rel=1e-13) and val("R") == pytest.approx([R], rel=1e-13)
     assert val("B") == pytest.approx(B, rel=1e-13)
     assert abs(B[0] - unchanged) > 1e-3 * unchanged  # the writes really entered the solve
     assert val("C") == pytest.approx(Cc, rel=1e-13) and val("D") == pytest.approx(D, rel=1e-13)
+    assert val("E") == pytest.approx(E, rel=1e-13) and val("F") == pytest.approx(F, rel=1e-13)
     su = 0.0
     for p in range(N ** 3):
         su += H.u[-1][p] * (1 + p % 13)
     assert val("U")[0] == su
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,L,nu", [(5, 4, 2), (3, 5, 1), (9, 4, 2)])
+def test_reference_test_mg_3d_fmg_start(tmp_path, c, L, nu):
+    """MG3D_USE_FMG=1: the unchanged test_mg_3d.c starts from the F-cycle guess of mg_dirichlet_analytic.c:771-806 (what
+    that monolith's fifth argument `useFMG` selects, :70-80, :984-988).  The first printed norms are the `fmg_*` golden
+    sequence, generated by replaying the reference's own operators (oracle/gen_golden.py)."""
+    if not os.path.exists(BIN1):
+        pytest.skip("oracle/_ref/dropin_test_mg_3d was not built")
+    V = np.load(os.path.join(ROOT, "tests", "golden", "vcycle.npz"))
+    want = V[f"norms_fmg_{c}_{L}_{nu}"]
+    env = dict(os.environ, OMP_NUM_THREADS="2", MG3D_USE_FMG="1")
+    r = subprocess.run([BIN1, str(c), str(L), str(nu)], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "Doing FMG Initialization....done" in r.stdout
+    got = history(r.stdout)
+    assert got[:len(want)] == pytest.approx(list(want), rel=6e-6)  # %g: 6 significant digits
+    plain = subprocess.run([BIN1, str(c), str(L), str(nu)], cwd=tmp_path, env=dict(os.environ, OMP_NUM_THREADS="2"),
+                           capture_output=True, text=True, timeout=600)
+    assert "FMG" not in plain.stdout and history(plain.stdout)[0] > 10 * got[0]  # the start really changed the run
 
 
 @pytest.mark.gpu

@@ -12,6 +12,9 @@ import hashlib
 import numpy as np
 import pytest
 
+import os
+
+import _oracle as O
 import multigrid_parallel_amd as M
 from multigrid_parallel_amd.binding import MG3D_D, MG3D_R, MG3D_U
 from test_gpu_parity import norm_rtol
@@ -67,6 +70,29 @@ def test_configs3_513_cubed_8_slabs_every_distributed_level():
             assert np.array_equal(d.download(MG3D_R, lvl), want[("r", lvl)]), f"r level {lvl}"
             if lvl < 6:
                 assert np.array_equal(d.download(MG3D_D, lvl), want[("d", lvl)]), f"d level {lvl}"
+
+
+@pytest.mark.parametrize("c,L", [(3, 9), (17, 6), (33, 2), (17, 2)])
+def test_admissible_coarse_grids_bit_exact_against_oracle(c, L):
+    """The coarse grids mg_3d.h:123,163 admits beyond the 9^3 of the headline: `3 9 2` (513^3 through NINE levels, SURVEY
+    8(d)'s alternative spelling), `17 6 2` (513^3 over a 17^3 coarse grid: 4913 unknowns, half-band 289 -- the wide-band
+    solve kernel), and two-level cycles over 33^3 (35937 unknowns, half-band 1089, the largest the reference's
+    assert(n*n < INT_MAX) lets through) and 17^3.  Two V(2,2) cycles, the whole solution vector against the oracle."""
+    nu = 2
+    N = (c - 1) * (1 << (L - 1)) + 1
+    O.lib().orc_set_threads(min(16, os.cpu_count() or 1))
+    want_norms, want_u, want_init, _ = O.run_problem(c, L, nu, 2)
+    O.lib().orc_set_threads(1)
+    with M.Solver(c, L, nu) as s:
+        s.setup_test_problem()
+        init = s.get_initial_residual()
+        got = s.vcycles(2)
+        u = s.download(MG3D_U, L - 1)
+    assert init == pytest.approx(want_init, rel=1e-12)
+    assert np.array_equal(u, want_u)
+    np.testing.assert_allclose(got, want_norms, rtol=norm_rtol(N), atol=0)
+    if (c, L) == (3, 9):
+        np.testing.assert_allclose(got, [3.86147e+07, 4.68671e+06], rtol=3e-2)  # same problem as `9 7 2`, other hierarchy
 
 
 def _digest(a):
