@@ -338,11 +338,18 @@ def main():
         solver.vcycles(1)  # priming: the sweep launcher measures its chunk lengths on first use; the problem is set up again
         init = solver.setup_test_problem()
         warm_norms = solver.vcycles(args.warmup)
+        solver.timing_enable(True)  # per-phase event pairs on the library's streams (no host stall inside the batch)
         barrier(solver)
         t0 = time.perf_counter()
         norms = solver.vcycles(args.steps)
         barrier(solver)
         elapsed = time.perf_counter() - t0
+        phase_ms = dict(solver.timing(), rank=rank)
+        solver.timing_enable(False)
+        per_rank = [phase_ms]
+        if dist.is_initialized():
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, phase_ms)
         if dist.is_initialized():
             t = torch.tensor([elapsed], dtype=torch.float64,
                              device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -405,6 +412,11 @@ def main():
                 "first_norm": float(norms[0]), "last_norm": float(norms[-1]), "initial_rhs_norm": init,
                 "rccl_ranks": rccl_ranks, "halo_overlap": overlap,
                 "ranks": [{"rank": r, "device": d, "name": n} for r, d, n in placement],
+                # where each rank's cycle went (ms per cycle, event pairs inside the timed region): kernels on its slabs,
+                # exchanges on the compute stream, exchanges overlapped on the communication stream, coarse levels
+                "per_rank_ms": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in pr.items()} for pr in per_rank],
+                "coarse_policy": "rank 0 only (MG3D_COARSE_GATHER=1)" if os.environ.get("MG3D_COARSE_GATHER") == "1"
+                else "replicated on every rank",
                 "history_matches_reference": known_ok,
                 "slabs_bit_identical_to_single_domain": slabs_ok,
                 # no per-kernel timers on the slab path: the whole cycle against the aggregate HBM peak (the
@@ -431,8 +443,8 @@ def main():
 
     warm_norms = solver.vcycles(args.warmup)
     solver.timing_reset()
-    # event pairs for the finest level's launches only, carried by the dispatches themselves (no marker packets, no
-    # host stall): mode 3.  --breakdown: every stage and kernel of every level (markers: ~5 us of idle queue each)
+    # event pairs around the finest level's launches only (mode 3: 8 marker packets per cycle, ~5 us of idle queue each,
+    # no host stall).  --breakdown: every stage and kernel of every level
     solver.timing_enable(1 if args.breakdown else args.timing_mode)
     barrier(solver)
     t0 = time.perf_counter()
@@ -497,7 +509,7 @@ def main():
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": dom["counter_bytes"],
             "frac_definition": "compulsory bytes of the launch (inputs read once + outputs written once) / mean launch "
-                               "duration (HIP event pairs bound to the dispatches, this run's timed region) / 8 TB/s; "
+                               "duration (HIP event pairs on the library's stream, this run's timed region) / 8 TB/s; "
                                "<= 1 by construction.  frac_survey_credit: the same time against SURVEY 8(d)'s credited "
                                "bytes (1.5 n w per fused colour pass), may exceed 1 and is not a bandwidth",
             "traffic_source": "HBM-side bytes per launch from rocprofv3 PMC passes committed as profiles/pmc_traffic.json "

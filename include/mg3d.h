@@ -117,7 +117,7 @@ int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level);
 
 /* per-stage timers (timing_info.h:6-47), filled from hipEvent pairs recorded in-stream (no stall).
  * on: 0 = off, 1 = every level, 2 = finest level only, 3 = the kernel timers of the finest level only (no stage
- * timers; the fused-sweep launches carry their event pair in the dispatch itself: no marker packets in the queue). */
+ * timers: a third of the marker packets, what bench.py's roofline object needs). */
 int mg3d_timing_enable(mg3d_ctx *ctx, int on);
 int mg3d_timing_reset(mg3d_ctx *ctx);
 int mg3d_timing_get(mg3d_ctx *ctx, int level, int stage, int *num_calls, double *seconds);
@@ -182,6 +182,48 @@ int mg3d_dist_sync(mg3d_dist *d);
 int mg3d_slab_halo(int smooth_iters);
 int mg3d_slab_first_level(int coarse_pts, int num_levels, int nranks, int halo);
 int mg3d_slab_owned(int coarse_pts, int num_levels, int nranks, int halo, int level, int rank, int *lo, int *hi);
+
+/* The exchange plan of ONE V-cycle for one rank (pure host arithmetic, usable without a GPU): every transfer the rank
+ * takes part in, in issue order.  The library's own transports (RCCL and loopback) execute exactly this list -- they hold
+ * no plane arithmetic of their own -- so a property checked on the plans of all ranks (every send has its receive with the
+ * same count, offsets inside the slab and on the same global planes, every rank walks the same phases) is a property of
+ * what runs on the GPUs.  What each phase stands for in the reference: the implicit barrier at the end of an orphaned
+ * `omp for` (mg_3d.h:658-702, 807-842, 961-995, 1007-1145), after which every thread sees its neighbours' planes.
+ * A phase = one ncclGroupStart/End (all ranks issue the same phases in the same order); offsets and counts are in planes
+ * of `plane_elems` elements: LOCAL plane indices of the rank's slab for distributed levels, global ones for the
+ * replicated level's arrays.  stream: 0 compute stream / first communicator, 1 communication stream / second
+ * communicator (overlap = 1 only).  policy bit 0: the coarse levels are solved on rank 0 only (right-hand side gathered,
+ * correction broadcast: MG3D_COARSE_GATHER=1) instead of replicated on every rank behind one all-gather. */
+enum { MG3D_XK_HALO_U_DOWN = 0, /* u_l after pre-smoothing + restriction, for the prolongation on the way up */
+       MG3D_XK_HALO_D,          /* d_(l-1) after restriction */
+       MG3D_XK_RHS_ALLGATHER,   /* d of the first replicated level: one broadcast per owner */
+       MG3D_XK_RHS_GATHER,      /* policy bit 0: the same planes to rank 0 only */
+       MG3D_XK_CORR_BCAST,      /* policy bit 0: u of the first replicated level from rank 0 */
+       MG3D_XK_HALO_U_UP,       /* u_(l-1), the coarse correction, before the prolongation into level l */
+       MG3D_XK_HALO_U_NEXT,     /* finest u after post-smoothing, halo planes 2..H, for the next cycle */
+       MG3D_XK_NORM,            /* per-rank sums of squares, all-gathered */
+       MG3D_XK_COUNT };
+enum { MG3D_XOP_SEND = 0, MG3D_XOP_RECV, MG3D_XOP_BCAST, MG3D_XOP_ALLGATHER };
+typedef struct mg3d_xfer {
+    int phase;       /* 0, 1, ... in issue order within the cycle */
+    int kind;        /* MG3D_XK_* */
+    int op;          /* MG3D_XOP_* */
+    int peer;        /* send/recv: the other rank; broadcast: the root; all-gather: -1 */
+    int field, level;
+    int offset;      /* first plane (send: source, recv: destination, broadcast: both) */
+    int count;       /* planes */
+    long long plane_elems;
+    int stream;
+} mg3d_xfer;
+/* returns the number of entries (out may be NULL to ask for it), or a negative MG3D_ERR_* */
+int mg3d_dist_plan(int coarse_pts, int num_levels, int nranks, int smooth_iters, int rank, int overlap, int policy,
+                   mg3d_xfer *out, int max_entries);
+/* per-phase cost of the slab path, from event pairs on the streams the phases run on (on = 1; off by default):
+ * ms[0] whole cycles, ms[1] exchanges on the compute stream, ms[2] exchanges on the communication stream (overlapped),
+ * ms[3] the replicated (or rank-0) coarse levels incl. the direct solve; kernels on the distributed levels =
+ * ms[0] - ms[1] - ms[3].  Sums since the last enable; *cycles = cycles covered. */
+int mg3d_dist_timing_enable(mg3d_dist *d, int on);
+int mg3d_dist_timing_get(mg3d_dist *d, double ms[4], int *cycles);
 
 /* ------------------------------------- host-pointer forms (reference signatures)
  * Same argument meaning as the reference functions; data is staged to the

@@ -453,6 +453,20 @@ class DistSolver:
     def sync(self):
         check(self.L.mg3d_dist_sync(self._h))
 
+    def timing_enable(self, on=True):
+        check(self.L.mg3d_dist_timing_enable(self._h, int(on)))
+
+    def timing(self):
+        """per-cycle means since timing_enable(True): whole cycle, exchanges on the compute stream, exchanges on the
+        communication stream (overlapped), the replicated / rank-0 coarse levels; kernels on the distributed levels are
+        what is left of the cycle"""
+        ms = (C.c_double * 4)()
+        n = C.c_int(0)
+        check(self.L.mg3d_dist_timing_get(self._h, ms, C.byref(n)))
+        k = max(1, n.value)
+        return {"cycles": n.value, "cycle_ms": ms[0] / k, "exchange_ms": ms[1] / k, "exchange_overlapped_ms": ms[2] / k,
+                "replicated_ms": ms[3] / k, "kernels_ms": (ms[0] - ms[1] - ms[3]) / k}
+
 
 def PF(a):
     if a is None:

@@ -26,6 +26,7 @@ struct mg3d_ctx {
     hipStream_t stream;
     bool own_stream; /* false when a distributed driver shares one stream between contexts */
     LuBand lu;
+    LuBand lu_in; /* the factor without its identity rows (n == 0: not built), see install_lu */
     bool have_lu;
     double *lu_work;  /* 2n doubles */
     double *partials; /* MG3D_MAX_PARTIALS doubles */

@@ -108,60 +108,25 @@ static void resolve_timers(mg3d_ctx *ctx)
 }
 
 /* scoped event pair: a stage of the reference's timing table, or (kernel = true) one kernel launch.
- * embed = true (kernel scopes that wrap exactly ONE fused-sweep launch): no marker packets; the pair is published for
- * launch_sweep, which binds it to the dispatch itself (mg3d_internal.h, LaunchEvents).  timing: 1 every level, 2 the
- * finest level, 3 the finest level's kernel scopes only (what bench.py's roofline needs, at the least cost). */
-static bool timing_embed()
-{
-    static const bool off = getenv("MG3D_TIMING_EMBED") && getenv("MG3D_TIMING_EMBED")[0] == '0';
-    return !off;
-}
-
+ * timing: 1 every level, 2 the finest level, 3 the finest level's kernel scopes only (what bench.py's roofline needs: 8
+ * marker packets per cycle instead of 24; each costs ~5 us of idle queue, 0.09 against 0.04 ms of a 3.3 ms cycle.  Binding
+ * the pair to the dispatch itself, hipExtLaunchKernelGGL, measured the same 0.04 ms as the 8 markers: not kept). */
 struct StageScope {
     mg3d_ctx *ctx;
     mg3d_ctx::Pending p;
-    bool on, embedded;
-    LaunchEvents le, *prev;
-    StageScope(mg3d_ctx *c, int l, int s, bool kernel = false, bool embed = false) : ctx(c), embedded(false), prev(nullptr)
+    bool on;
+    StageScope(mg3d_ctx *c, int l, int s, bool kernel = false) : ctx(c)
     {
         p.slot = kernel ? c->L * MG3D_NUM_STAGES + l * MG3D_NUM_KERNELS + s : l * MG3D_NUM_STAGES + s;
         p.a = p.b = nullptr;
         on = ctx->timing == 1 || (ctx->timing == 2 && l == ctx->L - 1) || (ctx->timing == 3 && kernel && l == ctx->L - 1);
-        if (!on)
-            return;
-        if (kernel && embed && timing_embed()) {
-            p.a = take_event(ctx);
-            p.b = take_event(ctx);
-            if (p.a && p.b) {
-                embedded = true;
-                le = LaunchEvents{p.a, p.b, false};
-                prev = mg3d_launch_events;
-                mg3d_launch_events = &le;
-                return;
-            }
-            if (p.a)
-                ctx->event_pool.push_back(p.a);
-            if (p.b)
-                ctx->event_pool.push_back(p.b);
-            p.a = p.b = nullptr;
-        }
-        if ((p.a = take_event(ctx)))
+        if (on && (p.a = take_event(ctx)))
             (void)hipEventRecord(p.a, ctx->stream);
     }
     ~StageScope()
     {
         if (!on)
             return;
-        if (embedded) {
-            mg3d_launch_events = prev;
-            if (le.used) {
-                ctx->pending.push_back(p);
-            } else { /* nothing was launched inside the scope */
-                ctx->event_pool.push_back(p.a);
-                ctx->event_pool.push_back(p.b);
-            }
-            return;
-        }
         if ((p.b = take_event(ctx)))
             (void)hipEventRecord(p.b, ctx->stream);
         ctx->pending.push_back(p);
@@ -169,23 +134,22 @@ struct StageScope {
 };
 
 
+static void free_band(LuBand &b)
+{
+    for (double *p : {b.lcol, b.ucol, b.diag, b.lrot, b.urot, b.stream})
+        if (p)
+            (void)hipFree(p);
+    if (b.in_map)
+        (void)hipFree(b.in_map);
+    memset(&b, 0, sizeof b);
+}
+
 static void free_lu(mg3d_ctx *ctx)
 {
-    if (ctx->lu.lcol)
-        (void)hipFree(ctx->lu.lcol);
-    if (ctx->lu.ucol)
-        (void)hipFree(ctx->lu.ucol);
-    if (ctx->lu.diag)
-        (void)hipFree(ctx->lu.diag);
-    if (ctx->lu.lrot)
-        (void)hipFree(ctx->lu.lrot);
-    if (ctx->lu.urot)
-        (void)hipFree(ctx->lu.urot);
-    if (ctx->lu.stream)
-        (void)hipFree(ctx->lu.stream);
+    free_band(ctx->lu);
+    free_band(ctx->lu_in);
     if (ctx->lu_work)
         (void)hipFree(ctx->lu_work);
-    memset(&ctx->lu, 0, sizeof ctx->lu);
     ctx->lu_work = nullptr;
     ctx->have_lu = false;
 }
@@ -229,6 +193,7 @@ static mg3d_ctx *ctx_new(int L, int iters)
     ctx->iters = iters;
     ctx->have_lu = false;
     memset(&ctx->lu, 0, sizeof ctx->lu);
+    memset(&ctx->lu_in, 0, sizeof ctx->lu_in);
     ctx->lu_work = nullptr;
     ctx->partials = ctx->sumsq = ctx->h_sumsq = nullptr;
     ctx->sumsq_slots = 0;
@@ -354,17 +319,16 @@ extern "C" int mg3d_ctx_set_smooth_iters(mg3d_ctx *ctx, int iters)
 }
 
 /* --------------------------------------------------------------- coarse LU */
-/* Banded, column-major copy of a dense row-major LU factor for the device solve:
+/* Banded, column-major copy of a row-major LU factor (entry (i, j) = at(i, j)) for the device solve:
  * bw = populated half bandwidth (max |i-j| with LU[i][j] != 0). */
-static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_doubles)
+template <class At> static int build_band(LuBand &out, long long n, At at)
 {
     int bw = 1;
     for (long long i = 0; i < n; i++) {
-        const double *row = LU + i * n;
         long long lo = 0, hi = n - 1;
-        while (lo < i && row[lo] == 0.)
+        while (lo < i && at(i, lo) == 0.)
             lo++;
-        while (hi > i && row[hi] == 0.)
+        while (hi > i && at(i, hi) == 0.)
             hi--;
         if (i - lo > bw)
             bw = (int)(i - lo);
@@ -375,7 +339,7 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
     int fast_div = 1;
     const long long npad = (n + 63) / 64 * 64;
     for (long long j = 0; j < n; j++) {
-        diag[j] = LU[j * n + j];
+        diag[j] = at(j, j);
         /* reciprocal for lu_div(): correctly rounded by the host's IEEE division; 0 = "divide the ordinary way" */
         const double ad = fabs(diag[j]);
         if (!(ad >= 0x1p-460 && ad <= 0x1p460))
@@ -384,23 +348,22 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
         for (int t = 0; t < bw; t++) {
             const long long il = j + 1 + t, iu = j - 1 - t;
             if (il < n)
-                lcol[j * bw + t] = LU[il * n + j];
+                lcol[j * bw + t] = at(il, j);
             if (iu >= 0)
-                ucol[j * bw + t] = LU[iu * n + j];
+                ucol[j * bw + t] = at(iu, j);
         }
     }
-    free_lu(ctx);
-    ctx->lu.n = (int)n;
-    ctx->lu.bw = bw;
-    ctx->lu.fast_div = fast_div;
-    ctx->lu.npad = (int)npad;
-    HIPCHK(hipMalloc(&ctx->lu.lcol, lcol.size() * sizeof(double)));
-    HIPCHK(hipMalloc(&ctx->lu.ucol, ucol.size() * sizeof(double)));
-    HIPCHK(hipMalloc(&ctx->lu.diag, diag.size() * sizeof(double)));
-    HIPCHK(hipMalloc(&ctx->lu_work, work_doubles * sizeof(double)));
-    HIPCHK(hipMemcpy(ctx->lu.lcol, lcol.data(), lcol.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->lu.ucol, ucol.data(), ucol.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->lu.diag, diag.data(), diag.size() * sizeof(double), hipMemcpyHostToDevice));
+    free_band(out);
+    out.n = (int)n;
+    out.bw = bw;
+    out.fast_div = fast_div;
+    out.npad = (int)npad;
+    HIPCHK(hipMalloc(&out.lcol, lcol.size() * sizeof(double)));
+    HIPCHK(hipMalloc(&out.ucol, ucol.size() * sizeof(double)));
+    HIPCHK(hipMalloc(&out.diag, diag.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(out.lcol, lcol.data(), lcol.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(out.ucol, ucol.data(), ucol.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(out.diag, diag.data(), diag.size() * sizeof(double), hipMemcpyHostToDevice));
     /* narrow bands (coarse grids up to 11^3): lane-rotated copies for the single-wave kernel */
     const int R = (bw + 63) / 64;
     if (R <= 2 && 4 * (size_t)n * sizeof(double) <= 60000) {
@@ -411,15 +374,15 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
                     const int tf = (int)((l - j - 1) & 63) + 64 * q, tb = (int)((j - 1 - l) & 63) + 64 * q;
                     const long long irow_f = j + 1 + tf, irow_b = j - 1 - tb;
                     if (tf < bw && irow_f < n)
-                        lrot[(size_t)j * 64 * R + 64 * q + l] = LU[irow_f * n + j];
+                        lrot[(size_t)j * 64 * R + 64 * q + l] = at(irow_f, j);
                     if (tb < bw && irow_b >= 0)
-                        urot[(size_t)j * 64 * R + 64 * q + l] = LU[irow_b * n + j];
+                        urot[(size_t)j * 64 * R + 64 * q + l] = at(irow_b, j);
                 }
-        HIPCHK(hipMalloc(&ctx->lu.lrot, lrot.size() * sizeof(double)));
-        HIPCHK(hipMalloc(&ctx->lu.urot, urot.size() * sizeof(double)));
-        HIPCHK(hipMemcpy(ctx->lu.lrot, lrot.data(), lrot.size() * sizeof(double), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(ctx->lu.urot, urot.data(), urot.size() * sizeof(double), hipMemcpyHostToDevice));
-        ctx->lu.rot_r = R;
+        HIPCHK(hipMalloc(&out.lrot, lrot.size() * sizeof(double)));
+        HIPCHK(hipMalloc(&out.urot, urot.size() * sizeof(double)));
+        HIPCHK(hipMemcpy(out.lrot, lrot.data(), lrot.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(out.urot, urot.data(), urot.size() * sizeof(double), hipMemcpyHostToDevice));
+        out.rot_r = R;
         /* stream for the loader/solver kernel (see lu_solve_stream_kernel) when its LDS ring fits */
         const int CH = mg3d_lu_stream_chunk((int)n, R);
         if (CH > 0) {
@@ -438,11 +401,57 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
                         st[(size_t)((npad + (npad - 1 - j)) * step_d + l * R + qb)] = urot[(size_t)j * 64 * R + 64 * q + l];
                     }
                 }
-            HIPCHK(hipMalloc(&ctx->lu.stream, st.size() * sizeof(double)));
-            HIPCHK(hipMemcpy(ctx->lu.stream, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice));
-            ctx->lu.stream_ch = CH;
+            HIPCHK(hipMalloc(&out.stream, st.size() * sizeof(double)));
+            HIPCHK(hipMemcpy(out.stream, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice));
+            out.stream_ch = CH;
         }
     }
+    return MG3D_OK;
+}
+
+static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_doubles)
+{
+    free_lu(ctx);
+    CHK(build_band(ctx->lu, n, [&](long long i, long long j) { return LU[i * n + j]; }));
+    HIPCHK(hipMalloc(&ctx->lu_work, work_doubles * sizeof(double)));
+    /* The reduced system.  A row of the factor that is the identity row (constructCoarseMatrixA's boundary rows,
+     * mg_3d.h:179-185; elimination leaves them alone) gives x[i] = b[i] in both substitutions, and when that b[i] is
+     * +-0 -- every boundary entry of a V-cycle's coarse right-hand side: the injected faces of a residual that is never
+     * written there, mg_3d.h:824-825, 879-958 -- its products with other rows' factors are +-0 and change no running sum
+     * (sums start at +0 and never become -0).  What is left is the factor restricted to the other rows (9^3: 343 of 729
+     * unknowns, half-band 49 instead of 81): the same values in the same order for every remaining term, i.e. the same
+     * bits, in less than half the strictly sequential steps.  The solve kernel checks the right-hand side and takes
+     * the full system whenever an identity row's entry is not a zero (the F-cycle start, host-pointer calls). */
+    const bool no_reduce = getenv("MG3D_LU_REDUCED") && getenv("MG3D_LU_REDUCED")[0] == '0'; /* read per factor: tests compare both */
+    if (no_reduce || !ctx->lu.stream_ch)
+        return MG3D_OK;
+    std::vector<int> map((size_t)n, -1), rows;
+    for (long long i = 0; i < n; i++) {
+        bool ident = LU[i * n + i] == 1.;
+        const long long lo = i - ctx->lu.bw < 0 ? 0 : i - ctx->lu.bw, hi = i + ctx->lu.bw >= n ? n - 1 : i + ctx->lu.bw;
+        for (long long j = lo; j <= hi && ident; j++)
+            ident = j == i || LU[i * n + j] == 0.;
+        if (!ident) {
+            map[(size_t)i] = (int)rows.size();
+            rows.push_back((int)i);
+        }
+    }
+    const long long ni = (long long)rows.size(), npad_in = (ni + 63) / 64 * 64;
+    if (getenv("MG3D_LU_LOG"))
+        fprintf(stderr, "mg3d lu: n %lld bw %d R %d, %lld rows are not identity rows (padded %lld of %d)\n", n, ctx->lu.bw,
+                ctx->lu.rot_r, ni, npad_in, ctx->lu.npad);
+    if (ni == 0 || ni == n || 2 * npad_in > ctx->lu.npad)
+        return MG3D_OK; /* nothing to gain, or the reduced vectors do not fit beside the full right-hand side in LDS */
+    CHK(build_band(ctx->lu_in, ni, [&](long long a, long long b) { return LU[(long long)rows[(size_t)a] * n + rows[(size_t)b]]; }));
+    if (!ctx->lu_in.stream_ch) {
+        free_band(ctx->lu_in);
+        return MG3D_OK;
+    }
+    if (getenv("MG3D_LU_LOG"))
+        fprintf(stderr, "mg3d lu: reduced factor n %d bw %d R %d stream %d\n", ctx->lu_in.n, ctx->lu_in.bw, ctx->lu_in.rot_r,
+                ctx->lu_in.stream_ch);
+    HIPCHK(hipMalloc(&ctx->lu.in_map, (size_t)n * sizeof(int)));
+    HIPCHK(hipMemcpy(ctx->lu.in_map, map.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
     return MG3D_OK;
 }
 
@@ -457,6 +466,7 @@ extern "C" int mg3d_ctx_set_lu(mg3d_ctx *ctx, const double *LU)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     CHK(install_lu(ctx, LU, n, 2 * (size_t)n));
     ctx->have_lu = true;
+    ctx->have_es = false; /* whatever factor was loaded before (mg3d_es_setup re-arms it after its own call) */
     return MG3D_OK;
 }
 
@@ -622,7 +632,7 @@ static int enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters
             int np;
             {
                 StageScope kt(ctx, level, S == 4 ? MG3D_K_SWEEP4 : S == 2 ? (res ? MG3D_K_SWEEP2_RES : MG3D_K_SWEEP2)
-                                                                          : MG3D_K_RESIDUAL, true, /* embed: one launch */ true);
+                                                                          : MG3D_K_RESIDUAL, true);
                 np = k_sweep(l.g, (zero_in && passes == 2 * iters) ? nullptr : l.f[MG3D_U], l.f[MG3D_D], l.alt,
                              (res && want_res == 2 && !rst) ? l.f[MG3D_R] : nullptr,
                              (res && need_norm) ? ctx->partials : nullptr,
@@ -756,7 +766,9 @@ extern "C" int mg3d_coarse_solve(mg3d_ctx *ctx)
         return fail(MG3D_ERR_ARG, "mg3d_coarse_solve: NULL context");
     if (!ctx->have_lu)
         return fail(MG3D_ERR_STATE, "mg3d_coarse_solve: no coarse LU set (mg3d_ctx_build_coarse / mg3d_ctx_set_lu)");
-    k_lu_solve(ctx->lu, ctx->lv[0].g, ctx->lv[0].f[MG3D_D], ctx->lv[0].f[MG3D_U], ctx->lu_work, ctx->stream);
+    if (ctx->have_es)
+        return fail(MG3D_ERR_STATE, "mg3d_coarse_solve: the context holds the mixed-boundary factor of mg3d_es_setup");
+    k_lu_solve(ctx->lu, ctx->lu_in, ctx->lv[0].g, ctx->lv[0].f[MG3D_D], ctx->lv[0].f[MG3D_U], ctx->lu_work, ctx->stream);
     return launch_ok("mg3d_coarse_solve");
 }
 
@@ -775,6 +787,9 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
 {
     if (!ctx->have_lu)
         return fail(MG3D_ERR_STATE, "mg3d_vcycle: no coarse LU set (mg3d_ctx_build_coarse / mg3d_ctx_set_lu)");
+    if (ctx->have_es)
+        return fail(MG3D_ERR_STATE, "mg3d_vcycle: the context holds the mixed-boundary factor of mg3d_es_setup "
+                                    "(mg3d_es_vcycles, or load the Dirichlet factor again)");
     hipStream_t s = ctx->stream;
     const int L = ctx->L;
     /* level 1 below the top of the cycle, small enough for one workgroup's LDS: two launches instead of five */
@@ -833,7 +848,7 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
             (void)hipMemsetAsync(l0.f[MG3D_U], 0, l0.elems * sizeof(double), s);
         StageScope t(ctx, 0, MG3D_ST_RECURSE);
         StageScope kt(ctx, 0, MG3D_K_COARSE_SOLVE, true);
-        k_lu_solve(ctx->lu, l0.g, l0.f[MG3D_D], l0.f[MG3D_U], ctx->lu_work, s); /* :1270 */
+        k_lu_solve(ctx->lu, ctx->lu_in, l0.g, l0.f[MG3D_D], l0.f[MG3D_U], ctx->lu_work, s); /* :1270 */
     }
     for (int l = 1; l <= q; l++) {
         Level &lev = ctx->lv[l];
@@ -937,9 +952,11 @@ extern "C" int mg3d_fmg_initialize(mg3d_ctx *ctx)
         return fail(MG3D_ERR_ARG, "mg3d_fmg_initialize: NULL context");
     if (!ctx->have_lu)
         return fail(MG3D_ERR_STATE, "mg3d_fmg_initialize: no coarse LU set");
+    if (ctx->have_es)
+        return fail(MG3D_ERR_STATE, "mg3d_fmg_initialize: the context holds the mixed-boundary factor of mg3d_es_setup");
     hipStream_t s = ctx->stream;
     k_fill_boundary(ctx->lv[0].g, ctx->lv[0].f[MG3D_U], ctx->lv[0].h, s);                                  /* :780 */
-    k_lu_solve(ctx->lu, ctx->lv[0].g, ctx->lv[0].f[MG3D_D], ctx->lv[0].f[MG3D_U], ctx->lu_work, s);         /* :783 */
+    k_lu_solve(ctx->lu, ctx->lu_in, ctx->lv[0].g, ctx->lv[0].f[MG3D_D], ctx->lv[0].f[MG3D_U], ctx->lu_work, s);         /* :783 */
     for (int l = 1; l < ctx->L; l++) {
         Level &lev = ctx->lv[l], &lc = ctx->lv[l - 1];
         k_prolong(lc.g, lc.f[MG3D_U], lev.g, lev.f[MG3D_U], s);                                              /* :795 */
@@ -1115,7 +1132,7 @@ extern "C" int mg3d_host_lu_solve(const double *LU, int n, const double *b, doub
     g.pitch = 1;
     g.plane = 1;
     g.ig0 = 0;
-    k_lu_solve(ctx->lu, g, db, dx, ctx->lu_work, ctx->stream);
+    k_lu_solve(ctx->lu, ctx->lu_in, g, db, dx, ctx->lu_work, ctx->stream);
     CHK(launch_ok("mg3d_host_lu_solve"));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(x, dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));

@@ -108,6 +108,139 @@ extern "C" int mg3d_slab_owned(int coarse_pts, int num_levels, int nranks, int h
     return MG3D_OK;
 }
 
+/* ---- the exchange plan (include/mg3d.h): who sends which planes to whom, phase by phase.  Host arithmetic only. */
+struct PlanGeom {
+    int c, L, P, nu, H, ld;
+};
+
+struct Plan {
+    std::vector<mg3d_xfer> e;
+    std::vector<int> begin;      /* first entry of phase p; begin[nphases] = e.size() */
+    std::vector<int> kind, level; /* what phase p is, also for a rank that takes no part in it */
+};
+
+static void slab_local(const PlanGeom &G, int level, int rank, int *own_lo, int *own_hi, long long *plane_elems)
+{
+    int glo = 0, ghi = 0;
+    mg3d_slab_owned(G.c, G.L, G.P, G.H, level, rank, &glo, &ghi);
+    const int h_lo = rank > 0 ? G.H : 0;
+    *own_lo = h_lo;
+    *own_hi = h_lo + (ghi - glo);
+    const int N = (G.c - 1) * (1 << level) + 1;
+    *plane_elems = (long long)mg3d_pitch_for(N) * N;
+}
+
+/* the coarse planes of the first replicated level (ld-1) that rank r restricts into: those under its owned fine planes */
+static void plan_coarse_range(const PlanGeom &G, int r, int *lo, int *hi)
+{
+    int flo = 0, fhi = 0;
+    mg3d_slab_owned(G.c, G.L, G.P, G.H, G.ld, r, &flo, &fhi);
+    const int Nc = ((G.c - 1) << (G.ld - 1)) + 1;
+    *lo = r == 0 ? 0 : flo / 2;
+    *hi = r == G.P - 1 ? Nc : fhi / 2;
+}
+
+/* Halo planes skip+1 .. H (counted from the slab's owned planes) of `field` on distributed level l from the neighbours'
+ * owned planes; skip = 0 is the whole halo.  Halo plane t of the upper side is the upper neighbour's t-th owned plane, of
+ * the lower side the lower neighbour's t-th from the top. */
+static void plan_halo(Plan &pl, const PlanGeom &G, int kind, int field, int level, int rank, int skip, int stream)
+{
+    const int phase = (int)pl.kind.size();
+    pl.begin.push_back((int)pl.e.size());
+    pl.kind.push_back(kind);
+    pl.level.push_back(level);
+    const int n = G.H - skip;
+    if (n <= 0)
+        return;
+    int lo, hi;
+    long long pe;
+    slab_local(G, level, rank, &lo, &hi, &pe);
+    if (rank + 1 < G.P) {
+        pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_SEND, rank + 1, field, level, hi - G.H, n, pe, stream});
+        pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_RECV, rank + 1, field, level, hi + skip, n, pe, stream});
+    }
+    if (rank > 0) {
+        pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_SEND, rank - 1, field, level, lo + skip, n, pe, stream});
+        pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_RECV, rank - 1, field, level, lo - G.H, n, pe, stream});
+    }
+}
+
+static int build_plan(Plan &pl, int c, int L, int P, int nu, int rank, int overlap, int policy)
+{
+    if (c < 3 || L < 2 || nu < 1 || P < 1 || rank < 0 || rank >= P)
+        return MG3D_ERR_ARG;
+    PlanGeom G{c, L, P, nu, mg3d_slab_halo(nu), 0};
+    G.ld = mg3d_slab_first_level(c, L, P, G.H);
+    if (G.ld >= L)
+        return MG3D_ERR_ARG;
+    pl = Plan();
+    const int lc = G.ld - 1, Nc = ((c - 1) << lc) + 1;
+    const long long pec = (long long)mg3d_pitch_for(Nc) * Nc;
+    const int cs = overlap ? 1 : 0;
+    auto open_phase = [&](int kind, int level) {
+        pl.begin.push_back((int)pl.e.size());
+        pl.kind.push_back(kind);
+        pl.level.push_back(level);
+        return (int)pl.kind.size() - 1;
+    };
+    for (int l = L - 1; l >= G.ld; l--) { /* down */
+        plan_halo(pl, G, MG3D_XK_HALO_U_DOWN, MG3D_U, l, rank, 0, cs);
+        if (l - 1 >= G.ld) {
+            plan_halo(pl, G, MG3D_XK_HALO_D, MG3D_D, l - 1, rank, 0, 0);
+        } else if (policy & 1) {
+            const int ph = open_phase(MG3D_XK_RHS_GATHER, lc);
+            for (int r = 1; r < P; r++) {
+                int lo, hi;
+                plan_coarse_range(G, r, &lo, &hi);
+                if (rank == r)
+                    pl.e.push_back(mg3d_xfer{ph, MG3D_XK_RHS_GATHER, MG3D_XOP_SEND, 0, MG3D_D, lc, lo, hi - lo, pec, 0});
+                if (rank == 0)
+                    pl.e.push_back(mg3d_xfer{ph, MG3D_XK_RHS_GATHER, MG3D_XOP_RECV, r, MG3D_D, lc, lo, hi - lo, pec, 0});
+            }
+        } else if (P > 1) {
+            const int ph = open_phase(MG3D_XK_RHS_ALLGATHER, lc);
+            for (int root = 0; root < P; root++) {
+                int lo, hi;
+                plan_coarse_range(G, root, &lo, &hi);
+                pl.e.push_back(mg3d_xfer{ph, MG3D_XK_RHS_ALLGATHER, MG3D_XOP_BCAST, root, MG3D_D, lc, lo, hi - lo, pec, 0});
+            }
+        } else {
+            open_phase(MG3D_XK_RHS_ALLGATHER, lc);
+        }
+    }
+    if (policy & 1) {
+        const int ph = open_phase(MG3D_XK_CORR_BCAST, lc);
+        if (P > 1)
+            pl.e.push_back(mg3d_xfer{ph, MG3D_XK_CORR_BCAST, MG3D_XOP_BCAST, 0, MG3D_U, lc, 0, Nc, pec, 0});
+    }
+    for (int l = G.ld; l < L; l++) { /* up */
+        if (l - 1 >= G.ld)
+            plan_halo(pl, G, MG3D_XK_HALO_U_UP, MG3D_U, l - 1, rank, 0, 0);
+        if (l == L - 1)
+            plan_halo(pl, G, MG3D_XK_HALO_U_NEXT, MG3D_U, l, rank, 1, cs);
+    }
+    {
+        const int ph = open_phase(MG3D_XK_NORM, L - 1);
+        if (P > 1)
+            pl.e.push_back(mg3d_xfer{ph, MG3D_XK_NORM, MG3D_XOP_ALLGATHER, -1, -1, L - 1, rank, 1, 1, 0});
+    }
+    pl.begin.push_back((int)pl.e.size());
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_dist_plan(int coarse_pts, int num_levels, int nranks, int smooth_iters, int rank, int overlap,
+                              int policy, mg3d_xfer *out, int max_entries)
+{
+    Plan pl;
+    const int rc = build_plan(pl, coarse_pts, num_levels, nranks, smooth_iters, rank, overlap, policy);
+    if (rc != MG3D_OK)
+        return rc < 0 ? rc : -rc;
+    if (out)
+        for (int i = 0; i < (int)pl.e.size() && i < max_entries; i++)
+            out[i] = pl.e[(size_t)i];
+    return (int)pl.e.size();
+}
+
 /* ------------------------------------------------------------------------------------- structures */
 struct SlabLevel {
     Level lv;
@@ -143,7 +276,70 @@ struct mg3d_dist {
     int norm_slots;
     std::vector<double> spacing; /* per level */
     double *selftest; /* MG3D_FORCE_COMM=1 on one rank: H planes of the finest level, target of the self-addressed receives */
+    /* the exchange plan of one cycle for every local rank (mg3d_dist_plan): the transports below execute it entry by
+     * entry and hold no plane arithmetic of their own */
+    std::vector<Plan> plans;
+    int phase;  /* next phase of the cycle being enqueued */
+    int policy; /* bit 0: coarse levels on rank 0 only (MG3D_COARSE_GATHER=1) */
+    /* per-phase cost (mg3d_dist_timing_enable): event pairs, resolved at the next synchronisation */
+    bool timing;
+    struct Timed {
+        int bucket; /* 0 cycle, 1 exchange on the compute stream, 2 exchange on the communication stream, 3 coarse levels */
+        hipEvent_t a, b;
+    };
+    std::vector<Timed> timed;
+    std::vector<hipEvent_t> ev_pool;
+    double t_ms[4];
+    int t_cycles;
 };
+
+static hipEvent_t dist_take_event(mg3d_dist *D)
+{
+    hipEvent_t e = nullptr;
+    if (!D->ev_pool.empty()) {
+        e = D->ev_pool.back();
+        D->ev_pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+        e = nullptr;
+    }
+    return e;
+}
+
+struct DistScope { /* event pair around a piece of the cycle on stream s */
+    mg3d_dist *D;
+    mg3d_dist::Timed t;
+    hipStream_t s;
+    DistScope(mg3d_dist *d, int bucket, hipStream_t st) : D(d), s(st)
+    {
+        t.bucket = bucket;
+        t.a = t.b = nullptr;
+        if (D->timing && (t.a = dist_take_event(D)))
+            (void)hipEventRecord(t.a, s);
+    }
+    ~DistScope()
+    {
+        if (!D->timing || !t.a)
+            return;
+        if ((t.b = dist_take_event(D)))
+            (void)hipEventRecord(t.b, s);
+        D->timed.push_back(t);
+    }
+};
+
+/* call only after the streams have been synchronised */
+static void dist_resolve_timers(mg3d_dist *D)
+{
+    for (auto &t : D->timed) {
+        float ms = 0.f;
+        if (t.a && t.b && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess)
+            D->t_ms[t.bucket] += ms;
+        if (t.a)
+            D->ev_pool.push_back(t.a);
+        if (t.b)
+            D->ev_pool.push_back(t.b);
+    }
+    D->timed.clear();
+}
 
 static SlabLevel &SL(mg3d_dist *D, RankState &R, int l) { return R.dl[l - D->ld]; }
 
@@ -176,6 +372,9 @@ extern "C" int mg3d_dist_destroy(mg3d_dist *D)
         (void)hipStreamSynchronize(D->comm_stream);
     if (D->stream)
         (void)hipStreamSynchronize(D->stream);
+    dist_resolve_timers(D);
+    for (auto e : D->ev_pool)
+        (void)hipEventDestroy(e);
     if (D->ev_ready)
         (void)hipEventDestroy(D->ev_ready);
     for (auto e : D->ev_u)
@@ -241,6 +440,12 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
     D->h_norms = D->d_norms = nullptr;
     D->comm_stream = nullptr;
     D->ev_ready = nullptr;
+    D->phase = 0;
+    D->timing = false;
+    D->t_cycles = 0;
+    for (double &x : D->t_ms)
+        x = 0.;
+    D->policy = (getenv("MG3D_COARSE_GATHER") && getenv("MG3D_COARSE_GATHER")[0] == '1') ? 1 : 0;
     /* Overlap of the large u exchanges with the coarser levels (second stream, second communicator).  Loopback:
      * on by default (plain stream concurrency).  RCCL: OFF by default -- two communicators driven concurrently
      * from two streams of one device have never run on more than one physical GPU here (one GPU per box), and
@@ -368,7 +573,47 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
             }
         }
     }
+    /* the plan every exchange below is read from; built after the overlap decision is final */
+    D->plans.resize(D->rs.size());
+    for (size_t ri = 0; ri < D->rs.size(); ri++) {
+        const int rc = build_plan(D->plans[ri], coarse_pts, num_levels, nranks, smooth_iters, D->rs[ri].rank,
+                                  D->overlap ? 1 : 0, D->policy);
+        if (rc != MG3D_OK) {
+            mg3d_dist_destroy(D);
+            return fail(rc, "mg3d_dist_create: no exchange plan for rank %d of %d", D->rs[ri].rank, nranks);
+        }
+    }
     *out = D;
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_dist_timing_enable(mg3d_dist *D, int on)
+{
+    if (!D)
+        return fail(MG3D_ERR_ARG, "mg3d_dist_timing_enable: NULL");
+    HIPCHK(hipStreamSynchronize(D->comm_stream));
+    HIPCHK(hipStreamSynchronize(D->stream));
+    dist_resolve_timers(D);
+    D->timing = on != 0;
+    if (on) {
+        for (double &x : D->t_ms)
+            x = 0.;
+        D->t_cycles = 0;
+    }
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_dist_timing_get(mg3d_dist *D, double ms[4], int *cycles)
+{
+    if (!D || !ms)
+        return fail(MG3D_ERR_ARG, "mg3d_dist_timing_get: NULL");
+    HIPCHK(hipStreamSynchronize(D->comm_stream));
+    HIPCHK(hipStreamSynchronize(D->stream));
+    dist_resolve_timers(D);
+    for (int i = 0; i < 4; i++)
+        ms[i] = D->t_ms[i];
+    if (cycles)
+        *cycles = D->t_cycles;
     return MG3D_OK;
 }
 
@@ -477,54 +722,93 @@ extern "C" int mg3d_dist_sync(mg3d_dist *D)
 }
 
 /* --------------------------------------------------------------------------------------- transport */
-/* Refresh the halo planes skip+1 .. H (counted from the slab's owned planes) of `field` on distributed level
- * l from the neighbours' owned planes; skip = 0 is the whole halo.  Halo plane t of the upper side is the
- * neighbour's owned plane t (t = 1: its first), of the lower side the lower neighbour's t-th from the top. */
-static int exchange_halo(mg3d_dist *D, int field, int l, hipStream_t s, int skip = 0)
+/* Executes the next phase of the cycle's plan for every local rank; `kind` / `level` say where the schedule believes it
+ * is -- a mismatch means schedule and plan have come apart, and nothing is sent.  RCCL: one group of the rank's
+ * sends / receives / broadcasts exactly as listed.  Loopback: every send is copied into the receive entry that names it
+ * in the peer's plan of the same phase (counts must agree), every broadcast range from the root's array into all others. */
+static int run_phase(mg3d_dist *D, int kind, int level, hipStream_t s)
 {
-    const int H = D->H, n = D->H - skip;
-    if (n <= 0)
-        return MG3D_OK;
+    const int ph = D->phase++;
+    for (auto &pl : D->plans)
+        if (ph >= (int)pl.kind.size() || pl.kind[(size_t)ph] != kind || pl.level[(size_t)ph] != level)
+            return fail(MG3D_ERR_STATE, "slab schedule and exchange plan out of step at phase %d (schedule: kind %d level %d)",
+                        ph, kind, level);
     if (D->P == 1) {
-        /* forced single-rank communicators (MG3D_FORCE_COMM=1): the same grouped send/receive, addressed to
-         * itself and landing in a scratch buffer -- a one-GPU self-test of the calls, streams and events */
-        if (D->have_comm && D->selftest) {
-            SlabLevel &a = SL(D, D->rs[0], l);
+        /* forced single-rank communicators (MG3D_FORCE_COMM=1): a grouped send/receive addressed to itself, landing in
+         * a scratch buffer -- a one-GPU self-test of the calls, streams and events */
+        const bool halo = kind == MG3D_XK_HALO_U_DOWN || kind == MG3D_XK_HALO_D || kind == MG3D_XK_HALO_U_UP ||
+                          kind == MG3D_XK_HALO_U_NEXT;
+        if (D->have_comm && D->selftest && halo) {
+            SlabLevel &a = SL(D, D->rs[0], level);
+            const int n = D->H - (kind == MG3D_XK_HALO_U_NEXT ? 1 : 0);
             const size_t cnt = (size_t)n * a.lv.g.plane;
+            const int field = kind == MG3D_XK_HALO_D ? MG3D_D : MG3D_U;
             ncclComm_t comm = (s == D->comm_stream && D->have_comm2) ? D->comm2 : D->comm;
             NCCLCHK(ncclGroupStart());
-            NCCLCHK(ncclSend(a.lv.f[field] + a.lv.g.plane * (a.own_lo + skip), cnt, ncclDouble, 0, comm, s));
+            NCCLCHK(ncclSend(a.lv.f[field] + a.lv.g.plane * a.own_lo, cnt, ncclDouble, 0, comm, s));
             NCCLCHK(ncclRecv(D->selftest, cnt, ncclDouble, 0, comm, s));
             NCCLCHK(ncclGroupEnd());
         }
         return MG3D_OK;
     }
+    DistScope timer(D, s == D->comm_stream ? 2 : 1, s);
+    auto base = [&](size_t ri, const mg3d_xfer &e) -> double * {
+        RankState &R = D->rs[ri];
+        return e.level >= D->ld ? SL(D, R, e.level).lv.f[e.field] : R.coarse->lv[e.level].f[e.field];
+    };
     if (D->loopback) {
-        for (int r = 0; r + 1 < D->P; r++) {
-            SlabLevel &a = SL(D, D->rs[r], l), &b = SL(D, D->rs[r + 1], l);
-            const size_t bytes = (size_t)n * a.lv.g.plane * sizeof(double);
-            /* r's upper halo <- first owned planes of r+1 ; (r+1)'s lower halo <- last owned planes of r */
-            HIPCHK(hipMemcpyAsync(a.lv.f[field] + a.lv.g.plane * (a.own_hi + skip),
-                                  b.lv.f[field] + b.lv.g.plane * (b.own_lo + skip), bytes, hipMemcpyDeviceToDevice,
-                                  s));
-            HIPCHK(hipMemcpyAsync(b.lv.f[field] + b.lv.g.plane * (b.own_lo - H),
-                                  a.lv.f[field] + a.lv.g.plane * (a.own_hi - H), bytes, hipMemcpyDeviceToDevice, s));
+        for (size_t ri = 0; ri < D->plans.size(); ri++) {
+            const Plan &pl = D->plans[ri];
+            for (int i = pl.begin[(size_t)ph]; i < pl.begin[(size_t)ph + 1]; i++) {
+                const mg3d_xfer &e = pl.e[(size_t)i];
+                if (e.op == MG3D_XOP_SEND) {
+                    const Plan &pp = D->plans[(size_t)e.peer];
+                    const mg3d_xfer *m = nullptr;
+                    for (int k = pp.begin[(size_t)ph]; k < pp.begin[(size_t)ph + 1]; k++) {
+                        const mg3d_xfer &c = pp.e[(size_t)k];
+                        if (c.op == MG3D_XOP_RECV && c.peer == D->rs[ri].rank && c.field == e.field && c.level == e.level) {
+                            if (m)
+                                return fail(MG3D_ERR_STATE, "exchange plan: two receives match one send (phase %d)", ph);
+                            m = &c;
+                        }
+                    }
+                    if (!m || m->count != e.count || m->plane_elems != e.plane_elems)
+                        return fail(MG3D_ERR_STATE, "exchange plan: send of rank %d to %d in phase %d has no receive of its size",
+                                    D->rs[ri].rank, e.peer, ph);
+                    HIPCHK(hipMemcpyAsync(base((size_t)e.peer, *m) + m->plane_elems * m->offset, base(ri, e) + e.plane_elems * e.offset,
+                                          (size_t)e.count * e.plane_elems * sizeof(double), hipMemcpyDeviceToDevice, s));
+                } else if (e.op == MG3D_XOP_BCAST && D->rs[ri].rank == e.peer) {
+                    for (size_t dst = 0; dst < D->plans.size(); dst++)
+                        if (dst != ri)
+                            HIPCHK(hipMemcpyAsync(base(dst, e) + e.plane_elems * e.offset, base(ri, e) + e.plane_elems * e.offset,
+                                                  (size_t)e.count * e.plane_elems * sizeof(double), hipMemcpyDeviceToDevice, s));
+                } else if (e.op == MG3D_XOP_ALLGATHER && ri == 0) {
+                    RankState &R0 = D->rs[0];
+                    for (int r = 0; r < D->P; r++)
+                        HIPCHK(hipMemcpyAsync(R0.gather + r, D->rs[(size_t)r].coarse->sumsq, sizeof(double), hipMemcpyDeviceToDevice, s));
+                }
+            }
         }
         return MG3D_OK;
     }
+    const Plan &pl = D->plans[0];
     RankState &R = D->rs[0];
-    SlabLevel &a = SL(D, R, l);
-    const size_t cnt = (size_t)n * a.lv.g.plane;
-    double *f = a.lv.f[field];
     ncclComm_t comm = (s == D->comm_stream && D->have_comm2) ? D->comm2 : D->comm;
     NCCLCHK(ncclGroupStart());
-    if (R.rank + 1 < D->P) {
-        NCCLCHK(ncclSend(f + a.lv.g.plane * (a.own_hi - H), cnt, ncclDouble, R.rank + 1, comm, s));
-        NCCLCHK(ncclRecv(f + a.lv.g.plane * (a.own_hi + skip), cnt, ncclDouble, R.rank + 1, comm, s));
-    }
-    if (R.rank > 0) {
-        NCCLCHK(ncclSend(f + a.lv.g.plane * (a.own_lo + skip), cnt, ncclDouble, R.rank - 1, comm, s));
-        NCCLCHK(ncclRecv(f + a.lv.g.plane * (a.own_lo - H), cnt, ncclDouble, R.rank - 1, comm, s));
+    for (int i = pl.begin[(size_t)ph]; i < pl.begin[(size_t)ph + 1]; i++) {
+        const mg3d_xfer &e = pl.e[(size_t)i];
+        const size_t cnt = (size_t)e.count * e.plane_elems;
+        if (e.op == MG3D_XOP_ALLGATHER) {
+            NCCLCHK(ncclAllGather(R.coarse->sumsq, R.gather, cnt, ncclDouble, comm, s));
+            continue;
+        }
+        double *p = base(0, e) + e.plane_elems * e.offset;
+        if (e.op == MG3D_XOP_SEND)
+            NCCLCHK(ncclSend(p, cnt, ncclDouble, e.peer, comm, s));
+        else if (e.op == MG3D_XOP_RECV)
+            NCCLCHK(ncclRecv(p, cnt, ncclDouble, e.peer, comm, s));
+        else
+            NCCLCHK(ncclBroadcast(p, p, cnt, ncclDouble, e.peer, comm, s));
     }
     NCCLCHK(ncclGroupEnd());
     return MG3D_OK;
@@ -532,15 +816,13 @@ static int exchange_halo(mg3d_dist *D, int field, int l, hipStream_t s, int skip
 
 /* Start refreshing the u halos of level l behind everything queued on the compute stream so far, without
  * holding the compute stream up; await_u() makes the compute stream wait for the arrival. */
-static int start_u_exchange(mg3d_dist *D, int l, int skip)
+static int start_u_exchange(mg3d_dist *D, int kind, int l)
 {
-    if (D->P == 1 && !D->selftest)
-        return MG3D_OK;
-    if (!D->overlap)
-        return exchange_halo(D, MG3D_U, l, D->stream, skip);
+    if (!D->overlap || (D->P == 1 && !D->selftest))
+        return run_phase(D, kind, l, D->stream);
     HIPCHK(hipEventRecord(D->ev_ready, D->stream));
     HIPCHK(hipStreamWaitEvent(D->comm_stream, D->ev_ready, 0));
-    CHK(exchange_halo(D, MG3D_U, l, D->comm_stream, skip));
+    CHK(run_phase(D, kind, l, D->comm_stream));
     HIPCHK(hipEventRecord(D->ev_u[l], D->comm_stream));
     D->u_pending[l] = 1;
     return MG3D_OK;
@@ -555,65 +837,18 @@ static int await_u(mg3d_dist *D, int l)
     return MG3D_OK;
 }
 
-/* every rank ends up with the complete d of the first replicated level (ld-1); rank r computed the
- * planes [b(r), b(r+1)) of it (b of level ld halved) */
-static int allgather_coarse_rhs(mg3d_dist *D)
-{
-    hipStream_t s = D->stream;
-    const int lc = D->ld - 1;
-    if (D->P == 1 && !D->have_comm) /* a forced single-rank communicator still runs the collective (self-test) */
-        return MG3D_OK;
-    auto range = [&](int r, int *lo, int *hi) {
-        int flo, fhi;
-        mg3d_slab_owned(D->c, D->L, D->P, D->H, D->ld, r, &flo, &fhi);
-        const int Nc = D->rs[0].coarse->lv[lc].g.N;
-        *lo = r == 0 ? 0 : flo / 2;
-        *hi = r == D->P - 1 ? Nc : fhi / 2;
-    };
-    if (D->loopback) {
-        for (int src = 0; src < D->P; src++) {
-            int lo, hi;
-            range(src, &lo, &hi);
-            const Geom &g = D->rs[src].coarse->lv[lc].g;
-            const size_t bytes = (size_t)(hi - lo) * g.plane * sizeof(double);
-            for (int dst = 0; dst < D->P; dst++)
-                if (dst != src)
-                    HIPCHK(hipMemcpyAsync(D->rs[dst].coarse->lv[lc].f[MG3D_D] + g.plane * lo,
-                                          D->rs[src].coarse->lv[lc].f[MG3D_D] + g.plane * lo, bytes,
-                                          hipMemcpyDeviceToDevice, s));
-        }
-        return MG3D_OK;
-    }
-    RankState &R = D->rs[0];
-    const Geom &g = R.coarse->lv[lc].g;
-    double *buf = R.coarse->lv[lc].f[MG3D_D];
-    NCCLCHK(ncclGroupStart());
-    for (int root = 0; root < D->P; root++) {
-        int lo, hi;
-        range(root, &lo, &hi);
-        NCCLCHK(ncclBroadcast(buf + g.plane * lo, buf + g.plane * lo, (size_t)(hi - lo) * g.plane, ncclDouble, root,
-                              D->comm, s));
-    }
-    NCCLCHK(ncclGroupEnd());
-    return MG3D_OK;
-}
-
 /* total = sum over ranks (in rank order, so every rank gets the same bits) of each rank's sumsq[0] */
 static int reduce_norm(mg3d_dist *D, int slot)
 {
     hipStream_t s = D->stream;
-    if (D->loopback) {
-        RankState &R0 = D->rs[0];
-        for (int r = 0; r < D->P; r++)
-            HIPCHK(hipMemcpyAsync(R0.gather + r, D->rs[r].coarse->sumsq, sizeof(double), hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(sum_in_order_kernel, dim3(1), dim3(64), 0, s, R0.gather, D->P, D->d_norms + slot);
-        return MG3D_OK;
-    }
+    CHK(run_phase(D, MG3D_XK_NORM, D->L - 1, s));
     RankState &R = D->rs[0];
-    if (D->have_comm)
-        NCCLCHK(ncclAllGather(R.coarse->sumsq, R.gather, 1, ncclDouble, D->comm, s));
-    else
-        HIPCHK(hipMemcpyAsync(R.gather, R.coarse->sumsq, sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (D->P == 1 || (!D->loopback && !D->have_comm)) {
+        if (D->P == 1 && D->have_comm) /* forced single-rank communicator: the collective itself (self-test) */
+            NCCLCHK(ncclAllGather(R.coarse->sumsq, R.gather, 1, ncclDouble, D->comm, s));
+        else
+            HIPCHK(hipMemcpyAsync(R.gather, R.coarse->sumsq, sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
     hipLaunchKernelGGL(sum_in_order_kernel, dim3(1), dim3(64), 0, s, R.gather, D->P, D->d_norms + slot);
     return MG3D_OK;
 }
@@ -659,7 +894,7 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
          * 0.63 + 0.57 ms as two launches): with a restriction behind it the residual gets its own launch */
         const bool res = last && want_res != 0 && S != 4 && !(S == 2 && tgt != nullptr && !k_sweep_fuse_rst2());
         if (S == 0 && refresh_u) { /* u is final; the pure residual launch below reads owned +-1 only */
-            CHK(start_u_exchange(D, l, 1));
+            CHK(start_u_exchange(D, MG3D_XK_HALO_U_NEXT, l));
             refresh_u = false;
         }
         for (size_t ri = 0; ri < D->rs.size(); ri++) {
@@ -711,7 +946,7 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
         first = false;
     }
     if (refresh_u) /* the last launch smoothed and took the norm in one go */
-        CHK(start_u_exchange(D, l, 1));
+        CHK(start_u_exchange(D, MG3D_XK_HALO_U_NEXT, l));
     return MG3D_OK;
 }
 
@@ -719,6 +954,10 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
 {
     hipStream_t s = D->stream;
     const int L = D->L, ld = D->ld;
+    D->phase = 0;
+    DistScope cycle_timer(D, 0, s);
+    if (D->timing)
+        D->t_cycles++;
     for (auto &R : D->rs)
         if (!R.coarse->have_lu)
             return fail(MG3D_ERR_STATE, "mg3d_dist_vcycles: no coarse LU set (mg3d_dist_build_coarse)");
@@ -758,28 +997,37 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
         }
         /* u of this level is final until the prolongation on the way up: refresh its halos underneath the
          * coarser levels */
-        CHK(start_u_exchange(D, l, 0));
+        CHK(start_u_exchange(D, MG3D_XK_HALO_U_DOWN, l));
         /* the coarser level starts from its right-hand side at once: only owned planes were produced */
         if (l - 1 < ld)
-            CHK(allgather_coarse_rhs(D));
+            CHK(run_phase(D, (D->policy & 1) ? MG3D_XK_RHS_GATHER : MG3D_XK_RHS_ALLGATHER, ld - 1, s));
         else
-            CHK(exchange_halo(D, MG3D_D, l - 1, s));
+            CHK(run_phase(D, MG3D_XK_HALO_D, l - 1, s));
     }
-    /* ---- replicated levels: the ordinary V-cycle from level ld-1 (its guess zeroed first, :1258) */
-    for (auto &R : D->rs) {
-        Level &lc = R.coarse->lv[ld - 1];
-        (void)hipMemsetAsync(lc.f[MG3D_U], 0, lc.elems * sizeof(double), s);
-        if (ld - 1 == 0)
-            CHK(mg3d_coarse_solve(R.coarse));
-        else
-            CHK(mg3d_enqueue_vcycle(R.coarse, ld - 1, R.coarse->sumsq_slots - 1));
+    /* ---- replicated levels: the ordinary V-cycle from level ld-1 (its guess zeroed first, :1258), on every rank -- or,
+     * with MG3D_COARSE_GATHER=1, on rank 0 alone, whose correction is then broadcast (same bits either way: the ranks
+     * would have computed identical copies) */
+    {
+        DistScope timer(D, 3, s);
+        for (auto &R : D->rs) {
+            if ((D->policy & 1) && R.rank != 0)
+                continue;
+            Level &lc = R.coarse->lv[ld - 1];
+            (void)hipMemsetAsync(lc.f[MG3D_U], 0, lc.elems * sizeof(double), s);
+            if (ld - 1 == 0)
+                CHK(mg3d_coarse_solve(R.coarse));
+            else
+                CHK(mg3d_enqueue_vcycle(R.coarse, ld - 1, R.coarse->sumsq_slots - 1));
+        }
     }
+    if (D->policy & 1)
+        CHK(run_phase(D, MG3D_XK_CORR_BCAST, ld - 1, s));
     /* ---- up */
     for (int l = ld; l < L; l++) {
         /* :1331 on every local plane, halos included: the correction's halos (post-smoothed on owned +-1 only)
          * are refreshed first, those of u have been under way since the pre-smoother */
         if (l - 1 >= ld)
-            CHK(exchange_halo(D, MG3D_U, l - 1, s));
+            CHK(run_phase(D, MG3D_XK_HALO_U_UP, l - 1, s));
         CHK(await_u(D, l));
         const int want = l == L - 1 ? 1 : 0;
         const bool fold = dist_split_up_leg(D, 1, want);
@@ -799,6 +1047,8 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
         CHK(stage_smooth(D, l, 1, want, nullptr, false, l == L - 1, fold ? pro.data() : nullptr));
     }
     CHK(reduce_norm(D, slot));
+    if (D->phase != (int)D->plans[0].kind.size())
+        return fail(MG3D_ERR_STATE, "slab schedule ended after %d of the plan's %d phases", D->phase, (int)D->plans[0].kind.size());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(MG3D_ERR_HIP, "mg3d_dist_vcycles: kernel launch failed: %s", hipGetErrorString(e));
@@ -819,6 +1069,17 @@ extern "C" int mg3d_dist_vcycles(mg3d_dist *D, int count, double *norms)
         CHK(dist_finish(D));
         HIPCHK(hipMemcpyAsync(D->h_norms, D->d_norms, nb * sizeof(double), hipMemcpyDeviceToHost, D->stream));
         HIPCHK(hipStreamSynchronize(D->stream));
+        HIPCHK(hipStreamSynchronize(D->comm_stream));
+        dist_resolve_timers(D);
+        /* an RCCL failure that surfaced asynchronously (a peer died, a transport error): an error here, not a hang or a
+         * wrong number later */
+        for (ncclComm_t cm : {D->have_comm ? D->comm : nullptr, D->have_comm2 ? D->comm2 : nullptr})
+            if (cm) {
+                ncclResult_t ae = ncclSuccess;
+                NCCLCHK(ncclCommGetAsyncError(cm, &ae));
+                if (ae != ncclSuccess)
+                    return fail(MG3D_ERR_HIP, "RCCL reported an asynchronous error: %s", ncclGetErrorString(ae));
+            }
         if (norms)
             for (int c = 0; c < nb; c++)
                 norms[done + c] = sqrt(D->h_norms[c]);

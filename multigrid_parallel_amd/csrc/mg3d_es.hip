@@ -174,10 +174,13 @@ extern "C" int mg3d_es_setup(mg3d_ctx *ctx, const mg3d_es_params *p)
         return fail(MG3D_ERR_ARG, "mg3d_es_setup: the context was created with grid length %g, the problem has %g", ctx->length,
                     p->length);
     ctx->es = *p;
-    ctx->have_es = true;
-    for (auto &l : ctx->lv)
-        for (int f = 0; f < 3; f++)
+    for (int lv = 0; lv < ctx->L; lv++) {
+        Level &l = ctx->lv[lv];
+        for (int f = 0; f < 3; f++) {
             HIPCHK(hipMemsetAsync(l.f[f], 0, l.elems * sizeof(double), ctx->stream));
+            mg3d_ctx_touched(ctx, f, lv); /* written from outside the cycle: the coarse faces are injected afresh */
+        }
+    }
     const int top = ctx->L - 1;
     {
         const int N0 = ctx->lv[0].g.N;
@@ -189,10 +192,11 @@ extern "C" int mg3d_es_setup(mg3d_ctx *ctx, const mg3d_es_params *p)
             return fail(MG3D_ERR_ALLOC, "mg3d_es_setup: out of host memory");
         mg3d_es_coarse_matrix(A, N0, ctx->lv[0].h, p); /* mg_3d.h:287: spacing of the coarsest level */
         mg3d_lu_factor(A, (int)n);
-        const int rc = mg3d_ctx_set_lu(ctx, A);
+        const int rc = mg3d_ctx_set_lu(ctx, A); /* clears have_es: the factor now loaded is ... */
         free(A);
         CHK(rc);
     }
+    ctx->have_es = true; /* ... the mixed-boundary one: mg3d_vcycle* / mg3d_fmg_initialize / mg3d_coarse_solve refuse it */
     es_fill(ctx, top, 1.);
     return launch_ok_es("mg3d_es_setup");
 }
@@ -208,6 +212,8 @@ extern "C" int mg3d_es_smooth(mg3d_ctx *ctx, int level, int post, int iters)
 static int es_vcycle(mg3d_ctx *ctx, int q, int slot)
 {
     hipStream_t s = ctx->stream;
+    if (!ctx->have_es || !ctx->have_lu) /* mg3d_ctx_set_lu / mg3d_ctx_build_coarse since the set-up: Dirichlet factor loaded */
+        return fail(MG3D_ERR_STATE, "mg3d_es_vcycles: the context's coarse factor is not the mixed-boundary one (mg3d_es_setup)");
     for (int l = q; l >= 1; l--) {
         Level &lev = ctx->lv[l], &lc = ctx->lv[l - 1];
         if (l < ctx->L - 1)
@@ -221,7 +227,7 @@ static int es_vcycle(mg3d_ctx *ctx, int q, int slot)
         Level &l0 = ctx->lv[0];
         if (0 < ctx->L - 1)
             HIPCHK(hipMemsetAsync(l0.f[MG3D_U], 0, l0.elems * sizeof(double), s));
-        k_lu_solve(ctx->lu, l0.g, l0.f[MG3D_D], l0.f[MG3D_U], ctx->lu_work, s); /* :1270 */
+        k_lu_solve(ctx->lu, ctx->lu_in, l0.g, l0.f[MG3D_D], l0.f[MG3D_U], ctx->lu_work, s); /* :1270 */
         es_color(ctx, 0, 0, false);                                             /* the ghost copies, both colours */
         es_color(ctx, 0, 1, false);
     }

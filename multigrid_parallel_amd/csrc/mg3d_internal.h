@@ -41,19 +41,12 @@ struct LuBand {
      * loaders may over-read; a step is 64 lanes x rot_r doubles, [lane][q] */
     int stream_ch; /* 64 when built, else 0 */
     double *stream;
+    /* full factor only, when a reduced factor (the system without its identity rows) exists beside it: index of
+     * unknown p in the reduced system, -1 for an identity row (mg3d_ctx.hip, install_lu) */
+    int *in_map;
 };
 
 #define MG3D_MAX_PARTIALS 32768
-
-/* Launch timing without extra packets in the queue: a kernel timer scope (mg3d_ctx.hip) that wraps exactly one fused
- * sweep launch publishes its event pair here; launch_sweep hands the pair to hipExtLaunchKernelGGL, which binds both to
- * the dispatch itself (start/end of that kernel) instead of recording two marker packets around it -- each marker costs
- * ~5 us of idle queue (24 of them per cycle were 0.1 ms of a 3.3 ms cycle).  MG3D_TIMING_EMBED=0: markers again. */
-struct LaunchEvents {
-    hipEvent_t a, b;
-    bool used;
-};
-extern thread_local LaunchEvents *mg3d_launch_events;
 
 /* launchers (mg3d_kernels.hip); all asynchronous on `s` */
 void k_smooth_color(const Geom &g, double *v, const double *d, double hSq, int color, hipStream_t s);
@@ -96,6 +89,6 @@ void k_tiny_up(const Geom &g, double *u, const double *d, const Geom &gc, const 
 /* b and x are level-0 grids in the padded layout g0; work holds 2n doubles */
 /* steps per chunk of the streamed solve for n unknowns and rot_r = R on the current device, 0 if it cannot run */
 int mg3d_lu_stream_chunk(int n, int R);
-void k_lu_solve(const LuBand &lu, const Geom &g0, const double *b_pad, double *x_pad, double *work, hipStream_t s);
+void k_lu_solve(const LuBand &lu, const LuBand &lu_in /* reduced factor; n == 0: none */, const Geom &g0, const double *b_pad, double *x_pad, double *work, hipStream_t s);
 
 #endif

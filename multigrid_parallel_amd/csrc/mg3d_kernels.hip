@@ -13,6 +13,9 @@
 
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+
 #define WAVE 64
 
 __device__ __forceinline__ long long gidx(const Geom &g, int i, int j, int k)
@@ -760,28 +763,16 @@ __device__ __forceinline__ void lu_stream_pass(const double *ring, int first_chu
     }
 }
 
+/* The three waves' work once b[0..npad) and dg[0..2 npad) sit in LDS (no barrier after filling them yet): waves 1 and 2
+ * stream the factors through the two-slot ring, wave 0 substitutes forward into z and backward into b.  Ends with a
+ * workgroup barrier: b then holds the solution. */
 template <int R>
-__global__ void __launch_bounds__(192) lu_solve_stream_kernel(LuBand lu, Geom g0, const double *__restrict__ b_pad,
-                                                             double *__restrict__ x_pad)
+__device__ __forceinline__ void lu_stream_solve(const LuBand &lu, double *ring, double *b, double *z, const double *dg,
+                                                int lane, int wave)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int CD = 64 * 64 * R;  /* doubles per chunk */
     constexpr int NV = CD / 2 / 128; /* 16-byte vectors per loader lane per chunk (two loader waves) */
-    const int tid = threadIdx.x, lane = tid & 63, n = lu.n, npad = lu.npad;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nch = npad / 64, T = 2 * nch;
-    double *ring = lds, *b = lds + 2 * CD, *z = b + npad, *dg = z + npad; /* x overwrites b; dg: diagonal, reciprocals */
-    const int NN = g0.nj * g0.nk;
-    auto pad_of = [&](int p) -> long long {
-        const int i = p / NN, rem = p - i * NN;
-        const int j = rem / g0.nk, k = rem - j * g0.nk;
-        return g0.plane * i + (long long)g0.pitch * j + k;
-    };
-    for (int p = tid; p < npad; p += 192) {
-        b[p] = p < n ? b_pad[pad_of(p)] : 0.;
-        dg[p] = lu.diag[p];
-        dg[npad + p] = lu.diag[npad + p];
-    }
+    const int npad = lu.npad, nch = npad / 64, T = 2 * nch;
     if (wave != 0) {
         typedef double v2d __attribute__((ext_vector_type(2)));
         const int at = (wave - 1) * 64 + lane;
@@ -818,6 +809,62 @@ __global__ void __launch_bounds__(192) lu_solve_stream_kernel(LuBand lu, Geom g0
             lu_stream_pass<R, false, false>(ring, nch, nch, npad, lane, z, b, dg);
     }
     __syncthreads();
+}
+
+/* RI > 0: a reduced factor `lin` (the system without its identity rows, R = RI) exists beside the full one.  It is taken
+ * when every identity row's right-hand side entry is +-0 -- then those unknowns are x = b and contribute +-0 to every
+ * other row's running sums, which changes none of them (install_lu, mg3d_ctx.hip) -- else the full system. */
+template <int R, int RI>
+__global__ void __launch_bounds__(192) lu_solve_stream_kernel(LuBand lu, LuBand lin, Geom g0, const double *__restrict__ b_pad,
+                                                             double *__restrict__ x_pad)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int CD = 64 * 64 * R; /* doubles per chunk of the full system's ring (the reduced one's is not larger) */
+    const int tid = threadIdx.x, lane = tid & 63, n = lu.n, npad = lu.npad;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *ring = lds, *b = lds + 2 * CD, *z = b + npad, *dg = z + npad; /* x overwrites b; dg: diagonal, reciprocals */
+    const int NN = g0.nj * g0.nk;
+    auto pad_of = [&](int p) -> long long {
+        const int i = p / NN, rem = p - i * NN;
+        const int j = rem / g0.nk, k = rem - j * g0.nk;
+        return g0.plane * i + (long long)g0.pitch * j + k;
+    };
+    int nonzero = 0;
+    for (int p = tid; p < npad; p += 192) {
+        const double v = p < n ? b_pad[pad_of(p)] : 0.;
+        b[p] = v;
+        if (RI > 0 && p < n)
+            nonzero |= lu.in_map[p] < 0 && (__double_as_longlong(v) << 1) != 0ll;
+    }
+    if constexpr (RI > 0) {
+        if (!__syncthreads_or(nonzero)) { /* workgroup-uniform */
+            const int ni = lin.n, npi = lin.npad; /* 2 * npi <= npad (install_lu): both vectors fit into z's place */
+            double *bi = z, *zi = z + npi;
+            for (int p = tid; p < npi; p += 192) {
+                bi[p] = 0.;
+                dg[p] = lin.diag[p];
+                dg[npi + p] = lin.diag[npi + p];
+            }
+            __syncthreads();
+            for (int p = tid; p < n; p += 192) {
+                const int q = lu.in_map[p];
+                if (q >= 0)
+                    bi[q] = b[p];
+            }
+            (void)ni;
+            lu_stream_solve<RI>(lin, ring, bi, zi, dg, lane, wave);
+            for (int p = tid; p < n; p += 192) {
+                const int q = lu.in_map[p];
+                x_pad[pad_of(p)] = q >= 0 ? bi[q] : b[p]; /* identity row: x = (b - (+0)) / 1 = b, the sign of a zero kept */
+            }
+            return;
+        }
+    }
+    for (int p = tid; p < npad; p += 192) {
+        dg[p] = lu.diag[p];
+        dg[npad + p] = lu.diag[npad + p];
+    }
+    lu_stream_solve<R>(lu, ring, b, z, dg, lane, wave);
     for (int p = tid; p < n; p += 192)
         x_pad[pad_of(p)] = b[p];
 }
@@ -836,20 +883,31 @@ int mg3d_lu_stream_chunk(int n, int R)
     return lu_stream_lds((n + 63) / 64 * 64, R) <= (size_t)max_lds ? 64 : 0;
 }
 
-template <int R>
-static bool launch_lu_stream(const LuBand &lu, const Geom &g0, const double *b_pad, double *x_pad, hipStream_t s)
+template <int R, int RI>
+static bool launch_lu_stream(const LuBand &lu, const LuBand &lin, const Geom &g0, const double *b_pad, double *x_pad,
+                             hipStream_t s)
 {
     const size_t lds = lu_stream_lds(lu.npad, R);
-    static bool ready = false, ok = false;
-    if (!ready) { /* a slot ring beyond 64 KB has to be asked for once per kernel */
-        ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&lu_solve_stream_kernel<R>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess || lds <= 65536;
-        (void)hipGetLastError();
-        ready = true;
+    /* a slot ring beyond 64 KB has to be asked for, per kernel and per device: exactly what is needed (the kernel's few
+     * static bytes -- the workgroup vote -- count against the same 160 KB) */
+    if (lds > 65536) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        static std::mutex mu;
+        static std::map<int, size_t> granted; /* device -> bytes granted; 0 = refused */
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = granted.find(dev);
+        if (it == granted.end() || (it->second != 0 && it->second < lds)) {
+            const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&lu_solve_stream_kernel<R, RI>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+            (void)hipGetLastError();
+            granted[dev] = ok ? lds : 0;
+            it = granted.find(dev);
+        }
+        if (it->second == 0)
+            return false;
     }
-    if (!ok)
-        return false;
-    hipLaunchKernelGGL((lu_solve_stream_kernel<R>), dim3(1), dim3(192), lds, s, lu, g0, b_pad, x_pad);
+    hipLaunchKernelGGL((lu_solve_stream_kernel<R, RI>), dim3(1), dim3(192), lds, s, lu, lin, g0, b_pad, x_pad);
     return true;
 }
 
@@ -898,13 +956,20 @@ __global__ void __launch_bounds__(1024) lu_solve_block_kernel(LuBand lu, Geom g0
     }
 }
 
-void k_lu_solve(const LuBand &lu, const Geom &g0, const double *b_pad, double *x_pad, double *work, hipStream_t s)
+void k_lu_solve(const LuBand &lu, const LuBand &lu_in, const Geom &g0, const double *b_pad, double *x_pad, double *work,
+                hipStream_t s)
 {
     double *z = work, *acc = work + lu.n;
     const size_t lds = sizeof(double) * 4 * (size_t)lu.n;
-    if (lu.stream_ch == 64 && lu.rot_r == 2 && launch_lu_stream<2>(lu, g0, b_pad, x_pad, s))
+    /* the reduced factor rides along when it exists (narrower band: one row per lane) */
+    const bool red = lu.in_map && lu_in.n > 0 && lu_in.stream_ch == 64 && lu_in.rot_r == 1 && 2 * lu_in.npad <= lu.npad;
+    if (lu.stream_ch == 64 && lu.rot_r == 2 && red && launch_lu_stream<2, 1>(lu, lu_in, g0, b_pad, x_pad, s))
         return;
-    if (lu.stream_ch == 64 && lu.rot_r == 1 && launch_lu_stream<1>(lu, g0, b_pad, x_pad, s))
+    if (lu.stream_ch == 64 && lu.rot_r == 2 && launch_lu_stream<2, 0>(lu, lu, g0, b_pad, x_pad, s))
+        return;
+    if (lu.stream_ch == 64 && lu.rot_r == 1 && red && launch_lu_stream<1, 1>(lu, lu_in, g0, b_pad, x_pad, s))
+        return;
+    if (lu.stream_ch == 64 && lu.rot_r == 1 && launch_lu_stream<1, 0>(lu, lu, g0, b_pad, x_pad, s))
         return;
     if (lu.rot_r == 1)
         hipLaunchKernelGGL(lu_solve_wave_kernel<1>, dim3(1), dim3(64), lds, s, lu, g0, b_pad, x_pad);

@@ -44,8 +44,6 @@
  */
 #include "mg3d_internal.h"
 
-#include <hip/hip_ext.h>
-
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -56,8 +54,6 @@
 #include <vector>
 
 #define WAVE 64
-
-thread_local LaunchEvents *mg3d_launch_events = nullptr;
 
 struct SweepArgs {
     Geom g;
@@ -780,15 +776,8 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
         /* (measured in isolation, grouping 0 sometimes wins by 2 %; inside the cycle it then loses 5 %: not tuned) */
         a.xcd_remap = xcd_forced ? atoi(xcd_env) : nb < 64 ? 0 : nb <= ncu ? 1 : 2;
     };
-    auto launch = [&](bool final = false) {
-        LaunchEvents *ev = final ? mg3d_launch_events : nullptr; /* the one launch the caller's timer scope is about */
-        if (ev && !ev->used) {
-            hipExtLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO, RST>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s,
-                                  ev->a, ev->b, 0, a);
-            ev->used = true;
-        } else {
-            hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO, RST>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
-        }
+    auto launch = [&]() {
+        hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO, RST>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
     };
     if (getenv("MG3D_SWEEP_BALANCED") && getenv("MG3D_SWEEP_BALANCED")[0] == '1') {
         /* experiment: equal shares of the linearised (tile column, plane) space, one block per CU, no lock-step */
@@ -800,7 +789,7 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
         a.xcd_remap = nb < 64 ? 0 : 1;
         if (a.partials && nb > max_partials)
             return -1;
-        launch(true);
+        launch();
         return (int)nb;
     }
     /* Measured choice.  The model above ranks chunk lengths by steps; what a step costs depends on how many CUs stream
@@ -881,7 +870,7 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
     }
     if (a.partials && nb > max_partials)
         return -1;
-    launch(true);
+    launch();
     return (int)nb;
 }
 

@@ -13,6 +13,10 @@
  */
 #include "mg3d_internal.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #define TINY_MAX_N 17
 #define TINY_THREADS 1024
 
@@ -181,32 +185,56 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_up_kernel(Geom g, double *_
     }
 }
 
+/* Dynamic LDS above the 64 KB a kernel gets without asking (118 KB at 17^3) is granted per kernel AND per device: asked
+ * for once per (kernel, device), the answer remembered; a refusal (or a device whose opt-in limit is too small) sends the
+ * level through the generic kernels instead of failing at launch. */
+static bool tiny_lds_granted(const void *kernel, size_t lds)
+{
+    if (lds <= 65536)
+        return true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return false;
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> granted; /* bytes granted, 0 = refused */
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_pair(kernel, dev);
+    auto it = granted.find(key);
+    if (it == granted.end() || (it->second != 0 && it->second < lds)) {
+        int optin = 0;
+        bool ok = hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && (size_t)optin >= lds;
+        if (!ok && optin == 0) /* attribute not reported: let the grant itself decide */
+            ok = true;
+        ok = ok && hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        (void)hipGetLastError();
+        granted[key] = ok ? lds : 0;
+        it = granted.find(key);
+    }
+    return it->second != 0;
+}
+
+static size_t tiny_down_lds(const Geom &g) { return sizeof(double) * 3 * (size_t)g.N * g.N * g.N; }
+static size_t tiny_up_lds(const Geom &g, const Geom &gc)
+{
+    return sizeof(double) * (2 * (size_t)g.N * g.N * g.N + (size_t)gc.N * gc.N * gc.N);
+}
+
 bool k_tiny_fits(const Geom &g, const Geom &gc)
 {
-    return g.ig0 == 0 && g.ni == g.N && g.nj == g.N && g.nk == g.N && g.N >= 3 && g.N <= TINY_MAX_N && gc.N == (g.N + 1) / 2 &&
-           gc.ig0 == 0 && gc.ni == gc.N;
+    const bool shape = g.ig0 == 0 && g.ni == g.N && g.nj == g.N && g.nk == g.N && g.N >= 3 && g.N <= TINY_MAX_N &&
+                       gc.N == (g.N + 1) / 2 && gc.ig0 == 0 && gc.ni == gc.N;
+    return shape && tiny_lds_granted((const void *)tiny_down_kernel, tiny_down_lds(g)) &&
+           tiny_lds_granted((const void *)tiny_up_kernel, tiny_up_lds(g, gc));
 }
 
 void k_tiny_down(const Geom &g, double *u, const double *d, const double *r, const Geom &gc, double *dc, double h, int iters,
                  hipStream_t s)
 {
-    const size_t lds = sizeof(double) * 3 * (size_t)g.N * g.N * g.N;
-    static bool attr = false;
-    if (!attr) { /* 118 KB of dynamic LDS at 17^3: above the 64 KB a kernel gets without asking */
-        (void)hipFuncSetAttribute((const void *)tiny_down_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    hipLaunchKernelGGL(tiny_down_kernel, dim3(1), dim3(TINY_THREADS), lds, s, g, u, d, r, gc, dc, h * h, 1. / 6, 1. / (h * h),
-                       iters);
+    hipLaunchKernelGGL(tiny_down_kernel, dim3(1), dim3(TINY_THREADS), tiny_down_lds(g), s, g, u, d, r, gc, dc, h * h, 1. / 6,
+                       1. / (h * h), iters);
 }
 
 void k_tiny_up(const Geom &g, double *u, const double *d, const Geom &gc, const double *ec, double h, int iters, hipStream_t s)
 {
-    const size_t lds = sizeof(double) * (2 * (size_t)g.N * g.N * g.N + (size_t)gc.N * gc.N * gc.N);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)tiny_up_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    hipLaunchKernelGGL(tiny_up_kernel, dim3(1), dim3(TINY_THREADS), lds, s, g, u, d, gc, ec, h * h, 1. / 6, iters);
+    hipLaunchKernelGGL(tiny_up_kernel, dim3(1), dim3(TINY_THREADS), tiny_up_lds(g, gc), s, g, u, d, gc, ec, h * h, 1. / 6, iters);
 }

@@ -73,7 +73,21 @@ def test_lu_factor_band_skip_equals_dense_sweep_c9():
     O.lib().orc_coarse_matrix(O.P(B), 9, 0.125)
     M.lib().mg3d_lu_factor(P(A), n)
     O.lib().orc_lu_factor(O.P(B), n)
-    assert np.array_equal(A, B)
+    assert A.tobytes() == B.tobytes()
+
+
+def test_lu_factor_wide_band_c17_equals_oracle_byte_for_byte():
+    """c = 17 (4913 unknowns, half-band 289): the product's band-limited host factor against the oracle's, bytes (signed
+    zeros outside the band included); both are pinned to the dense sweep at c <= 9."""
+    n = 17 ** 3
+    A, B = np.zeros(n * n), np.zeros(n * n)
+    M.lib().mg3d_coarse_matrix(P(A), 17, 0.0625)
+    O.lib().orc_coarse_matrix(O.P(B), 17, 0.0625)
+    M.lib().mg3d_lu_factor(P(A), n)
+    O.lib().orc_set_threads(4)
+    O.lib().orc_lu_factor_banded(O.P(B), n)
+    O.lib().orc_set_threads(1)
+    assert A.tobytes() == B.tobytes()
 
 
 def test_vtk_writer_format(tmp_path):

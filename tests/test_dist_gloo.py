@@ -2,8 +2,9 @@
 send/recv for the halo planes, broadcast for the replicated right-hand side, all_gather for the norm.
 
 What is under test is the host logic the multi-GPU path rests on: the partition (`mg3d_slab_*` from libmg3d.so,
-pure host arithmetic), the halo depth H = 2*nu+2, and the exchange schedule of csrc/mg3d_dist.hip
-(dist_enqueue_vcycle), mirrored step by step below.  The per-slab arithmetic is the numpy statement of the
+pure host arithmetic), the halo depth H = 2*nu+2, and the EXCHANGE PLAN of csrc/mg3d_dist.hip (`mg3d_dist_plan`: the
+very list of sends / receives / broadcasts its RCCL transport issues, phase by phase) -- every transfer below is read
+from that plan, none is computed here; the order of the compute steps mirrors dist_enqueue_vcycle.  The per-slab arithmetic is the numpy statement of the
 operators (tests/_slab_numpy.py, pinned to the oracle); the replicated levels run the oracle's V-cycle.  The
 assembled solution must equal the single-domain oracle bit for bit.  No GPU, no HIP compute."""
 import ctypes as C
@@ -17,6 +18,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import _oracle as O
+import _plan as PL
 import _slab_numpy as S
 import multigrid_parallel_amd as M
 
@@ -45,29 +47,53 @@ class Slab:
         self.u, self.d, self.r = (np.zeros((self.ni, self.N, self.N)) for _ in range(3))
 
 
-def exchange(field, sl, r, P, H, skip=0):
-    """exchange_halo of mg3d_dist.hip: halo planes skip+1..H (counted from the owned planes) from the
-    neighbours' outermost owned planes."""
-    a = getattr(sl, field)
-    reqs, bufs = [], []
-    n = H - skip
-    if r + 1 < P:
-        reqs.append(dist.isend(torch.from_numpy(a[sl.own_hi - H:sl.own_hi - skip].copy()), r + 1))
-        up = torch.empty((n, sl.N, sl.N), dtype=torch.float64)
-        reqs.append(dist.irecv(up, r + 1))
-        bufs.append((up, slice(sl.own_hi + skip, sl.own_hi + H)))
-    if r > 0:
-        reqs.append(dist.isend(torch.from_numpy(a[sl.own_lo + skip:sl.own_lo + H].copy()), r - 1))
-        dn = torch.empty((n, sl.N, sl.N), dtype=torch.float64)
-        reqs.append(dist.irecv(dn, r - 1))
-        bufs.append((dn, slice(sl.own_lo - H, sl.own_lo - skip)))
-    for q in reqs:
-        q.wait()
-    for t, s in bufs:
-        a[s] = t.numpy()
+class PlanRunner:
+    """Executes the PRODUCT's exchange plan (mg3d_dist_plan -- the list the RCCL and loopback transports of
+    csrc/mg3d_dist.hip execute) over gloo: this test holds no plane arithmetic of its own for the transfers."""
+
+    def __init__(self, c, L, P, nu, r, policy=0):
+        self.ph = PL.phases(c, L, P, nu, r, 0, policy)
+        self.r, self.cur = r, 0
+
+    def start_cycle(self):
+        self.cur = 0
+
+    def run(self, kind, level, array_of, norm_part=None):
+        """next phase of the cycle; array_of(field, level) -> the (planes, N, N) array the entries index"""
+        es = self.ph.get(self.cur, [])
+        self.cur += 1
+        assert all(e.kind == kind and e.level == level for e in es), \
+            f"schedule and plan out of step: phase {self.cur - 1} is {[(PL.KIND_NAMES[e.kind], e.level) for e in es][:1]}, schedule wants {PL.KIND_NAMES[kind]} {level}"
+        reqs, landing, gathered = [], [], None
+        for e in es:
+            if e.op == PL.ALLGATHER:
+                parts = [torch.zeros(1, dtype=torch.float64) for _ in range(dist.get_world_size())]
+                dist.all_gather(parts, torch.tensor([norm_part], dtype=torch.float64))
+                gathered = [float(p) for p in parts]
+                continue
+            a = array_of(e.field, e.level)
+            pitch = (a.shape[2] + 15) // 16 * 16
+            assert e.plane_elems == pitch * a.shape[1]  # the device layout's padded plane
+            view = a[e.offset:e.offset + e.count]
+            assert view.shape[0] == e.count, "entry reaches outside the array"
+            if e.op == PL.SEND:
+                reqs.append(dist.isend(torch.from_numpy(view.copy()), e.peer))
+            elif e.op == PL.RECV:
+                t = torch.empty(view.shape, dtype=torch.float64)
+                reqs.append(dist.irecv(t, e.peer))
+                landing.append((t, view))
+            else:  # broadcast in place, root = peer
+                t = torch.from_numpy(view.copy())
+                dist.broadcast(t, src=e.peer)
+                view[:] = t.numpy()
+        for q in reqs:
+            q.wait()
+        for t, view in landing:
+            view[:] = t.numpy()
+        return gathered
 
 
-def worker(r, P, port, c, L, nu, cycles, out_path):
+def worker(r, P, port, c, L, nu, cycles, out_path, policy=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=r, world_size=P)
     lib = M.lib()
@@ -91,55 +117,63 @@ def worker(r, P, port, c, L, nu, cycles, out_path):
     top.u[:] = f3[top.ig0:top.ig0 + top.ni]
     top.d[:] = f3[top.ig0:top.ig0 + top.ni]
     norms = []
+    plan = PlanRunner(c, L, P, nu, r, policy)
+    Ncr = Hc.N[ld - 1]
+
+    def array_of(field, level):
+        if level >= ld:
+            return getattr(lv[level], "ud"[field])
+        return (Hc.u if field == 0 else Hc.d)[level].reshape(Ncr, Ncr, Ncr)
+
     for _ in range(cycles):
+        plan.start_cycle()
         for l in range(L - 1, ld - 1, -1):  # ---- down
             sl = lv[l]
             if l < L - 1:
                 sl.u[:] = 0.0
             S.smooth(sl.u, sl.d, hs[l], nu, False, sl.ig0, sl.N)
             S.residual(sl.u, sl.d, hs[l], sl.r, sl.ig0, sl.N)
-            # u of this level is final until the way up: its halos travel now (on the GPU: underneath the
-            # coarser levels, on the communication stream)
-            exchange("u", sl, r, P, H)
             if l - 1 >= ld:
                 sc = lv[l - 1]
                 S.restrict_planes(sl.r, sl.ig0, sl.N, sc.d, sc.ig0, sc.N, sc.own_lo, sc.own_hi)
-                exchange("d", sc, r, P, H)
             else:
-                Nc = Hc.N[ld - 1]
-                dc = Hc.d[ld - 1].reshape(Nc, Nc, Nc)
-                rng = []
-                for q in range(P):
-                    flo, fhi = owned(c, L, P, H, ld, q)
-                    rng.append((0 if q == 0 else flo // 2, Nc if q == P - 1 else fhi // 2))
-                S.restrict_planes(sl.r, sl.ig0, sl.N, dc, 0, Nc, rng[r][0], rng[r][1])
-                for q in range(P):  # allgather_coarse_rhs: one broadcast per owner
-                    t = torch.from_numpy(dc[rng[q][0]:rng[q][1]].copy())
-                    dist.broadcast(t, src=q)
-                    dc[rng[q][0]:rng[q][1]] = t.numpy()
-        # ---- replicated levels, identical on every rank
-        Hc.u[ld - 1][:] = 0.0
-        O.lib().orc_vcycle(Hc.ptrs(Hc.u), Hc.ptrs(Hc.d), Hc.ptrs(Hc.r), hs[ld - 1], ld - 1, L, nu, Hc.N[ld - 1], O.P(LU))
+                dc = Hc.d[ld - 1].reshape(Ncr, Ncr, Ncr)
+                flo, fhi = owned(c, L, P, H, ld, r)
+                S.restrict_planes(sl.r, sl.ig0, sl.N, dc, 0, Ncr, 0 if r == 0 else flo // 2, Ncr if r == P - 1 else fhi // 2)
+            # u of this level is final until the way up: its halos travel now (on the GPU: underneath the
+            # coarser levels, on the communication stream)
+            plan.run(PL.HALO_U_DOWN, l, array_of)
+            if l - 1 >= ld:
+                plan.run(PL.HALO_D, l - 1, array_of)
+            else:
+                plan.run(PL.RHS_GATHER if policy else PL.RHS_ALLGATHER, ld - 1, array_of)
+        # ---- coarse levels: identical on every rank -- or on rank 0 alone, whose correction is then broadcast
+        if not policy or r == 0:
+            Hc.u[ld - 1][:] = 0.0
+            O.lib().orc_vcycle(Hc.ptrs(Hc.u), Hc.ptrs(Hc.d), Hc.ptrs(Hc.r), hs[ld - 1], ld - 1, L, nu, Hc.N[ld - 1], O.P(LU))
+        else:
+            Hc.u[ld - 1][:] = np.nan  # must be overwritten by the broadcast
+        if policy:
+            plan.run(PL.CORR_BCAST, ld - 1, array_of)
         for l in range(ld, L):  # ---- up
             sl = lv[l]
             # the correction is applied to every local plane, halos included: both operands have exact halos
             if l - 1 >= ld:
                 sc = lv[l - 1]
-                exchange("u", sc, r, P, H)
+                plan.run(PL.HALO_U_UP, l - 1, array_of)
                 S.prolong_planes(sc.u, sc.ig0, sc.N, sl.u, sl.ig0, sl.N, 0, sl.ni)
             else:
-                Nc = Hc.N[ld - 1]
-                S.prolong_planes(Hc.u[ld - 1].reshape(Nc, Nc, Nc), 0, Nc, sl.u, sl.ig0, sl.N, 0, sl.ni)
+                S.prolong_planes(Hc.u[ld - 1].reshape(Ncr, Ncr, Ncr), 0, Ncr, sl.u, sl.ig0, sl.N, 0, sl.ni)
             S.smooth(sl.u, sl.d, hs[l], nu, True, sl.ig0, sl.N)  # no exchange: uses up 2*nu of the H halo planes
         # on the GPU the exchange below runs underneath the norm kernel, which reads the first halo plane:
         # that plane is left as the post-smoother produced it (exact), planes 2..H are refreshed
         top_before = top.u.copy()
-        exchange("u", top, r, P, H, skip=1)
+        plan.run(PL.HALO_U_NEXT, L - 1, array_of)
         ss = S.residual(top_before, top.d, hs[L - 1], None, top.ig0, top.N, top.own_lo, top.own_hi)
         assert ss == S.residual(top.u, top.d, hs[L - 1], None, top.ig0, top.N, top.own_lo, top.own_hi)
-        parts = [torch.zeros(1, dtype=torch.float64) for _ in range(P)]
-        dist.all_gather(parts, torch.tensor([ss], dtype=torch.float64))
-        norms.append(float(np.sqrt(sum(float(p) for p in parts))))
+        parts = plan.run(PL.NORM, L - 1, array_of, norm_part=ss)
+        assert plan.cur == len(plan.ph), "the cycle used every phase of the plan"
+        norms.append(float(np.sqrt(sum(parts))))
     # assemble the owned planes on rank 0
     mine = torch.from_numpy(top.u[top.own_lo:top.own_hi].copy())
     if r == 0:
@@ -157,12 +191,13 @@ def worker(r, P, port, c, L, nu, cycles, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("c,L,nu,P,min_planes", [(5, 5, 2, 2, 16), (5, 5, 1, 2, 8), (3, 6, 2, 3, 8), (3, 6, 2, 3, 16)])
-def test_slab_schedule_over_gloo(tmp_path, monkeypatch, c, L, nu, P, min_planes):
+@pytest.mark.parametrize("c,L,nu,P,min_planes,policy", [(5, 5, 2, 2, 16, 0), (5, 5, 1, 2, 8, 0), (3, 6, 2, 3, 8, 0), (3, 6, 2, 3, 16, 0),
+                                                        (5, 5, 2, 2, 16, 1), (3, 6, 2, 3, 8, 1)])
+def test_slab_schedule_over_gloo(tmp_path, monkeypatch, c, L, nu, P, min_planes, policy):
     monkeypatch.setenv("MG3D_SLAB_MIN_PLANES", str(min_planes))  # 8: thin slabs, three distributed levels
     cycles = 3
     out = str(tmp_path / "res.npz")
-    mp.spawn(worker, args=(P, free_port(), c, L, nu, cycles, out), nprocs=P, join=True)
+    mp.spawn(worker, args=(P, free_port(), c, L, nu, cycles, out, policy), nprocs=P, join=True)
     got = np.load(out)
     O.lib().orc_set_threads(1)
     want_norms, want_u, _, _ = O.run_problem(c, L, nu, cycles)

@@ -1,0 +1,137 @@
+"""The exchange plan the multi-GPU transports execute (mg3d_dist_plan, csrc/mg3d_dist.hip), checked WITHOUT a GPU for
+every rank of P = 2, 3, 4, 8: the RCCL transport issues exactly these entries (one ncclGroup per phase), so
+  * a send without its receive, or with another count, is the hang the first real multi-GPU run would die of;
+  * an offset outside the slab, or on other global planes than the peer's, is silent corruption.
+What a phase replaces in the reference: the implicit barrier that ends an orphaned `omp for` (mg_3d.h:658-702, 807-842,
+961-995, 1007-1145), after which every thread sees its neighbours' planes."""
+import ctypes as C
+
+import pytest
+
+import _plan as PL
+import multigrid_parallel_amd as M
+
+CONFIGS = [(9, 7, 2), (9, 8, 2), (5, 6, 3), (3, 7, 1), (9, 5, 1), (5, 7, 2)]
+
+
+def owned(c, L, P, H, level, r):
+    lo, hi = C.c_int(0), C.c_int(0)
+    assert M.lib().mg3d_slab_owned(c, L, P, H, level, r, C.byref(lo), C.byref(hi)) == 0
+    return lo.value, hi.value
+
+
+def slab(c, L, P, H, level, r):
+    glo, ghi = owned(c, L, P, H, level, r)
+    h_lo, h_hi = (H if r > 0 else 0), (H if r < P - 1 else 0)
+    return dict(ig0=glo - h_lo, ni=ghi - glo + h_lo + h_hi, own_lo=h_lo, own_hi=h_lo + ghi - glo)
+
+
+@pytest.mark.parametrize("policy", [0, 1])
+@pytest.mark.parametrize("overlap", [0, 1])
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
+@pytest.mark.parametrize("c,L,nu", CONFIGS)
+def test_every_send_has_its_receive(c, L, nu, P, overlap, policy):
+    lib = M.lib()
+    H = lib.mg3d_slab_halo(nu)
+    ld = lib.mg3d_slab_first_level(c, L, P, H)
+    if ld >= L:
+        pytest.skip("no level gives every rank enough planes")
+    plans = [PL.entries(c, L, P, nu, r, overlap, policy) for r in range(P)]
+    nph = {max(e.phase for e in p) + 1 for p in plans}
+    assert len(nph) == 1, "every rank walks the same number of phases"
+    nph = nph.pop()
+    Nc = (c - 1) * (1 << (ld - 1)) + 1
+    sent = recvd = 0
+    for ph in range(nph):
+        per = [[e for e in p if e.phase == ph] for p in plans]
+        kinds = {(e.kind, e.level, e.stream) for es in per for e in es}
+        assert len(kinds) == 1, f"phase {ph}: all ranks agree on what it is and on which stream it runs"
+        kind, level, stream = kinds.pop()
+        assert stream in (0, 1) and (stream == 0 or overlap == 1)
+        assert stream == (overlap if kind in (PL.HALO_U_DOWN, PL.HALO_U_NEXT) else 0)
+        for r in range(P):
+            for e in per[r]:
+                assert e.count > 0 and e.plane_elems > 0
+                if e.op == PL.SEND:
+                    sent += 1
+                    m = [x for x in per[e.peer] if x.op == PL.RECV and x.peer == r and x.field == e.field and x.level == e.level]
+                    assert len(m) == 1, f"phase {ph}: send {r}->{e.peer} has exactly one receive"
+                    m = m[0]
+                    assert (m.count, m.plane_elems) == (e.count, e.plane_elems)
+                    if e.level >= ld:  # slab to slab: in bounds, same global planes, owned -> halo
+                        a, b = slab(c, L, P, H, e.level, r), slab(c, L, P, H, e.level, e.peer)
+                        assert 0 <= e.offset and e.offset + e.count <= a["ni"]
+                        assert 0 <= m.offset and m.offset + m.count <= b["ni"]
+                        assert a["ig0"] + e.offset == b["ig0"] + m.offset
+                        assert a["own_lo"] <= e.offset and e.offset + e.count <= a["own_hi"], "only owned planes are sent"
+                        assert m.offset + m.count <= b["own_lo"] or m.offset >= b["own_hi"], "only halo planes are overwritten"
+                        assert abs(e.peer - r) == 1
+                    else:  # replicated arrays: global plane indices on both sides
+                        assert e.offset == m.offset and 0 <= e.offset and e.offset + e.count <= Nc
+                elif e.op == PL.RECV:
+                    recvd += 1
+                    m = [x for x in per[e.peer] if x.op == PL.SEND and x.peer == r and x.field == e.field and x.level == e.level]
+                    assert len(m) == 1, f"phase {ph}: receive {r}<-{e.peer} has exactly one send"
+        if kind in (PL.RHS_ALLGATHER, PL.CORR_BCAST):
+            lists = [[(e.op, e.peer, e.field, e.level, e.offset, e.count, e.plane_elems) for e in es] for es in per]
+            assert all(x == lists[0] for x in lists), "every rank issues the same broadcasts in the same order"
+            assert all(op == PL.BCAST for op, *_ in lists[0])
+            if kind == PL.RHS_ALLGATHER:
+                assert [x[1] for x in lists[0]] == list(range(P))
+                cover = 0
+                for _, root, _, _, off, cnt, _ in lists[0]:
+                    assert off == cover  # the owners' ranges tile the coarse level in rank order
+                    flo, fhi = owned(c, L, P, H, ld, root)
+                    assert off == (0 if root == 0 else flo // 2) and off + cnt == (Nc if root == P - 1 else fhi // 2)
+                    cover += cnt
+                assert cover == Nc
+            else:
+                assert lists[0] == [(PL.BCAST, 0, 0, ld - 1, 0, Nc, lists[0][0][6])]
+        if kind == PL.RHS_GATHER:
+            got = sorted((e.offset, e.offset + e.count) for e in per[0])
+            flo, fhi = owned(c, L, P, H, ld, 0)
+            cover = fhi // 2  # rank 0 restricted these itself
+            for a, b in got:
+                assert a == cover
+                cover = b
+            assert cover == Nc and all(e.op == PL.RECV for e in per[0])
+        if kind == PL.NORM:
+            assert ph == nph - 1 and [[(e.op, e.offset, e.count) for e in es] for es in per] == [[(PL.ALLGATHER, r, 1)] for r in range(P)]
+    assert sent == recvd > 0
+
+
+@pytest.mark.parametrize("c,L,nu,P", [(9, 7, 2, 8), (5, 6, 3, 3)])
+def test_phase_sequence_of_a_cycle(c, L, nu, P):
+    """the order dist_enqueue_vcycle walks: per distributed level u (for the way up), then the coarser right-hand side;
+    the coarse levels; per level the correction's halos; the finest u for the next cycle; the norm"""
+    lib = M.lib()
+    H = lib.mg3d_slab_halo(nu)
+    ld = lib.mg3d_slab_first_level(c, L, P, H)
+    seq = []
+    for e in PL.entries(c, L, P, nu, 1, 0, 0):
+        if not seq or seq[-1][0] != e.phase:
+            seq.append((e.phase, e.kind, e.level))
+    want = []
+    for l in range(L - 1, ld - 1, -1):
+        want.append((PL.HALO_U_DOWN, l))
+        want.append((PL.HALO_D, l - 1) if l - 1 >= ld else (PL.RHS_ALLGATHER, ld - 1))
+    for l in range(ld + 1, L):
+        want.append((PL.HALO_U_UP, l - 1))
+    want.append((PL.HALO_U_NEXT, L - 1))
+    want.append((PL.NORM, L - 1))
+    assert [(k, l) for _, k, l in seq] == want
+    assert [p for p, _, _ in seq] == list(range(len(want)))
+    # halo depth: H planes, except the end-of-cycle refresh that leaves the nearest plane alone
+    for e in PL.entries(c, L, P, nu, 1, 0, 0):
+        if e.kind in (PL.HALO_U_DOWN, PL.HALO_D, PL.HALO_U_UP):
+            assert e.count == H
+        if e.kind == PL.HALO_U_NEXT:
+            assert e.count == H - 1
+
+
+def test_plan_rejects_bad_arguments():
+    f = M.lib().mg3d_dist_plan
+    f.restype = C.c_int
+    assert f(9, 7, 8, 2, 8, 0, 0, None, 0) < 0   # rank out of range
+    assert f(9, 7, 0, 2, 0, 0, 0, None, 0) < 0
+    assert f(3, 3, 8, 2, 0, 0, 0, None, 0) < 0   # nothing can be distributed

@@ -237,7 +237,8 @@ def test_reference_test_mg_3d_fmg_start(tmp_path, c, L, nu):
     assert got[:len(want)] == pytest.approx(list(want), rel=6e-6)  # %g: 6 significant digits
     plain = subprocess.run([BIN1, str(c), str(L), str(nu)], cwd=tmp_path, env=dict(os.environ, OMP_NUM_THREADS="2"),
                            capture_output=True, text=True, timeout=600)
-    assert "FMG" not in plain.stdout and history(plain.stdout)[0] > 10 * got[0]  # the start really changed the run
+    assert "FMG" not in plain.stdout
+    assert history(plain.stdout)[0] > 1.5 * got[0]  # the start really changed the run
 
 
 @pytest.mark.gpu

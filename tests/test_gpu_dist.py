@@ -118,3 +118,34 @@ def test_overlap_and_sequential_exchange_agree(monkeypatch):
             res.append((d.vcycles(5), d.download(MG3D_U, 4)))
     assert np.array_equal(res[0][0], res[1][0])
     assert np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("c,L,nu,P,min_planes", [(5, 5, 2, 4, 8), (9, 5, 2, 8, 16), (3, 6, 2, 3, 8), (9, 5, 1, 2, 16)])
+def test_coarse_levels_on_rank_0_only(monkeypatch, c, L, nu, P, min_planes):
+    """MG3D_COARSE_GATHER=1 (the north-star's wording: "the coarsest level's direct solve is gathered to rank 0"): the
+    restricted right-hand side travels to rank 0, which alone runs the small levels and the gauss_elim.h solve and
+    broadcasts the correction.  Same bits as the default (every rank runs them redundantly behind one all-gather)."""
+    monkeypatch.setenv("MG3D_SLAB_MIN_PLANES", str(min_planes))
+    want_norms, want_u = single(c, L, nu, 4)
+    monkeypatch.setenv("MG3D_COARSE_GATHER", "1")
+    with M.DistSolver(c, L, nu, nranks=P) as d:
+        d.setup_test_problem()
+        norms = d.vcycles(4)
+        assert np.array_equal(d.download(MG3D_U, L - 1), want_u)
+    np.testing.assert_allclose(norms, want_norms, rtol=1e-11, atol=0)
+
+
+def test_slab_phase_timers(monkeypatch):
+    """mg3d_dist_timing_*: the per-phase split bench.py's N > 1 line reports per rank"""
+    with M.DistSolver(9, 5, 2, nranks=4) as d:
+        d.setup_test_problem()
+        d.vcycles(2)
+        d.timing_enable(True)
+        norms = d.vcycles(5)
+        t = d.timing()
+        d.timing_enable(False)
+        again = d.vcycles(1)
+    assert t["cycles"] == 5 and t["cycle_ms"] > 0
+    assert t["exchange_ms"] > 0 and t["replicated_ms"] > 0 and t["exchange_overlapped_ms"] > 0  # loopback overlaps by default
+    assert 0 < t["kernels_ms"] < t["cycle_ms"]
+    assert again[0] < norms[-1]

@@ -168,6 +168,60 @@ def test_lu_solve_numerators_outside_the_fast_division_window(c, kind):
     assert np.array_equal(np.signbit(got), np.signbit(want))
 
 
+@pytest.mark.parametrize("c", [5, 9])
+@pytest.mark.parametrize("kind", ["zero_faces", "negzero_faces", "mixed_zero_faces", "one_face_entry", "all_zero", "random_identity_rows"])
+def test_lu_solve_reduced_system_path(c, kind, monkeypatch):
+    """The direct solve drops the factor's identity rows (the boundary rows of constructCoarseMatrixA, mg_3d.h:179-185)
+    when every right-hand side entry on them is +-0 -- what a V-cycle hands it -- and takes the full system otherwise.
+    Both routes against the oracle, bit for bit and sign of zero for sign of zero, and against each other
+    (MG3D_LU_REDUCED=0: no reduced factor is built)."""
+    n = c ** 3
+    A = np.zeros(n * n)
+    O.lib().orc_coarse_matrix(O.P(A), c, 1.0 / (c - 1))
+    O.lib().orc_lu_factor(O.P(A), n)
+    rng = np.random.default_rng(17 * c)
+    b = rng.uniform(-1, 1, (c, c, c))
+    face = np.ones((c, c, c), dtype=bool)
+    face[1:-1, 1:-1, 1:-1] = False
+    if kind == "zero_faces":
+        b[face] = 0.0
+    elif kind == "negzero_faces":
+        b[face] = -0.0
+    elif kind == "mixed_zero_faces":
+        b[face] = np.where(rng.random(int(face.sum())) < 0.5, 0.0, -0.0)
+        b[1:-1, 1:-1, 1:-1][rng.random((c - 2,) * 3) < 0.3] = 0.0
+    elif kind == "one_face_entry":
+        b[face] = 0.0
+        b[c - 1, c // 2, c // 2] = 1e-300  # one entry on an identity row that is not a zero: the full system
+    elif kind == "all_zero":
+        b[:] = 0.0
+        b[face] = -0.0
+    b = b.reshape(-1).copy()
+    LU = A
+    if kind == "random_identity_rows":  # a generic banded factor with identity rows sprinkled in, zero entries on them
+        bw = 9
+        Ad = np.zeros((n, n))
+        ident = rng.random(n) < 0.55
+        for i in range(n):
+            if ident[i]:
+                Ad[i, i] = 1.0
+                continue
+            lo, hi = max(0, i - bw), min(n, i + bw + 1)
+            Ad[i, lo:hi] = rng.uniform(-1, 1, hi - lo)
+            Ad[i, i] = 2.0 * bw + 2.0
+        LU = Ad.reshape(-1).copy()
+        O.lib().orc_lu_factor(O.P(LU), n)
+        b[ident] = np.where(rng.random(int(ident.sum())) < 0.5, 0.0, -0.0)
+    want, got, full = np.zeros(n), np.zeros(n), np.zeros(n)
+    O.lib().orc_lu_solve(O.P(LU), n, O.P(b), O.P(want))
+    check(M.lib().mg3d_host_lu_solve(P(LU), n, P(b), P(got)))
+    monkeypatch.setenv("MG3D_LU_REDUCED", "0")
+    check(M.lib().mg3d_host_lu_solve(P(LU), n, P(b), P(full)))
+    for x in (got, full):
+        assert np.array_equal(x, want)
+        assert np.array_equal(np.signbit(x), np.signbit(want))
+
+
 def test_lu_solve_dense_random_matrix():
     # a full (non-banded) diagonally dominant factor: exercises the wide-band block kernel
     n = 200

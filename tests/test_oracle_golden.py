@@ -82,6 +82,39 @@ def test_coarse_matrix_and_lu_bit_exact(N):
     assert np.array_equal(x, G[f"lu_x_{N}"])
 
 
+@pytest.mark.parametrize("N", [3, 5, 9])
+def test_banded_lu_factor_equals_the_dense_sweep_byte_for_byte(N):
+    """orc_lu_factor_banded (used for the coarse grids the dense O(n^3) sweep cannot reach, c = 17 and 33) against the
+    pinned orc_lu_factor: same bytes, signed zeros included; and against the golden factors of the compiled reference."""
+    n = N ** 3
+    A = np.zeros(n * n)
+    O.lib().orc_coarse_matrix(O.P(A), N, 1.0 / (N - 1))
+    B = A.copy()
+    O.lib().orc_lu_factor(O.P(A), n)
+    O.lib().orc_set_threads(3)
+    O.lib().orc_lu_factor_banded(O.P(B), n)
+    assert A.tobytes() == B.tobytes()
+    if N == 9:
+        assert np.array_equal(sha(B), G["lu_sha_9"])
+
+
+@pytest.mark.parametrize("n,bl,bu,seed", [(60, 5, 9, 1), (97, 20, 3, 2), (130, 1, 1, 3), (64, 63, 63, 4), (75, 0, 7, 5)])
+def test_banded_lu_factor_random_bands(n, bl, bu, seed):
+    """random diagonally dominant band matrices with holes inside the band (exact zeros that fill in)"""
+    rng = np.random.default_rng(seed)
+    A = np.zeros((n, n))
+    for i in range(n):
+        for j in range(max(0, i - bl), min(n, i + bu + 1)):
+            if i == j or rng.uniform() < 0.6:
+                A[i, j] = rng.uniform(-1, 1)
+        A[i, i] = (-1) ** i * (np.abs(A[i]).sum() + 1.0)
+    A = A.reshape(-1).copy()
+    B = A.copy()
+    O.lib().orc_lu_factor(O.P(A), n)
+    O.lib().orc_lu_factor_banded(O.P(B), n)
+    assert A.tobytes() == B.tobytes()
+
+
 def test_lu_c9_bit_exact():
     n = 729
     A = np.zeros(n * n)

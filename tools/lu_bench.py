@@ -9,9 +9,15 @@ from multigrid_parallel_amd.binding import MG3D_D, MG3D_U
 
 c = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 rng = np.random.default_rng(1)
-with M.Solver(c, 6, 2) as s:      # levels c .. 257^3 (c = 9): the top level serves as the cache flusher
+for faces in ("random faces (full system)", "zero faces (reduced system, as in a V-cycle)"):
+  with M.Solver(c, 6, 2) as s:      # levels c .. 257^3 (c = 9): the top level serves as the cache flusher
     s.setup_test_problem()
-    s.upload(MG3D_D, 0, rng.uniform(-1, 1, c ** 3))
+    rhs = rng.uniform(-1, 1, (c, c, c))
+    if faces.startswith("zero"):
+        inner = rhs[1:-1, 1:-1, 1:-1].copy()
+        rhs[:] = 0.0
+        rhs[1:-1, 1:-1, 1:-1] = inner
+    s.upload(MG3D_D, 0, rhs.reshape(-1))
     for _ in range(5):
         s.coarse_solve()
     s.sync()
@@ -36,4 +42,4 @@ with M.Solver(c, 6, 2) as s:      # levels c .. 257^3 (c = 9): the top level ser
         flush(); s.coarse_solve()
     s.sync()
     cold = (time.perf_counter() - t0) / 50 - tf
-print(f"coarse solve {c}^3: back-to-back {warm * 1e6:.1f} us per launch, after a 257^3 sweep {cold * 1e6:.1f} us (sweep alone {tf * 1e6:.1f} us)")
+  print(f"coarse solve {c}^3, {faces}: back-to-back {warm * 1e6:.1f} us per launch, after a 257^3 sweep {cold * 1e6:.1f} us (sweep alone {tf * 1e6:.1f} us)")
