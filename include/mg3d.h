@@ -296,6 +296,10 @@ int mg3d32_fmg_initialize(mg3d32_ctx *ctx);
  * take the FULL N^3 float array. */
 typedef struct mg3d32_dist mg3d32_dist;
 int mg3d32_slab_halo(int smooth_iters);
+/* the exchange plan of this variant's V-cycle from distributed level q (the F-cycle start runs one from every level;
+ * want_norm = 0 leaves the norm phase out), same entry format and the same executor as mg3d_dist_plan; element = float */
+int mg3d32_dist_plan(int coarse_pts, int num_levels, int nranks, int smooth_iters, int rank, int q, int want_norm,
+                     mg3d_xfer *out, int max_entries);
 int mg3d32_dist_create(int coarse_pts, int num_levels, int smooth_iters, double omega, double grid_length, int rank,
                        int nranks, const void *unique_id, int device, mg3d32_dist **out);
 int mg3d32_dist_destroy(mg3d32_dist *d);

@@ -82,6 +82,10 @@ SIGNATURES = {
     "mg3d_slab_first_level": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mg3d_slab_owned": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                   C.POINTER(C.c_int)]),
+    "mg3d_dist_plan": (C.c_int, [C.c_int] * 7 + [C.c_void_p, C.c_int]),
+    "mg3d32_dist_plan": (C.c_int, [C.c_int] * 7 + [C.c_void_p, C.c_int]),
+    "mg3d_dist_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "mg3d_dist_timing_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mg3d_host_smooth": (C.c_int, [dp, dp, C.c_int, C.c_double, C.c_int, C.c_int]),
     "mg3d_host_residual": (C.c_int, [dp, dp, C.c_int, C.c_double, dp, dp]),
     "mg3d_host_restrict": (C.c_int, [dp, C.c_int, dp, C.c_int]),

@@ -41,6 +41,8 @@
 
 #include <rccl/rccl.h>
 
+#include "mg3d_plan.h"
+
 #define fail mg3d_fail
 #define HIPCHK(call)                                                                                    \
     do {                                                                                                \
@@ -108,87 +110,24 @@ extern "C" int mg3d_slab_owned(int coarse_pts, int num_levels, int nranks, int h
     return MG3D_OK;
 }
 
-/* ---- the exchange plan (include/mg3d.h): who sends which planes to whom, phase by phase.  Host arithmetic only. */
-struct PlanGeom {
-    int c, L, P, nu, H, ld;
-};
-
-struct Plan {
-    std::vector<mg3d_xfer> e;
-    std::vector<int> begin;      /* first entry of phase p; begin[nphases] = e.size() */
-    std::vector<int> kind, level; /* what phase p is, also for a rank that takes no part in it */
-};
-
-static void slab_local(const PlanGeom &G, int level, int rank, int *own_lo, int *own_hi, long long *plane_elems)
-{
-    int glo = 0, ghi = 0;
-    mg3d_slab_owned(G.c, G.L, G.P, G.H, level, rank, &glo, &ghi);
-    const int h_lo = rank > 0 ? G.H : 0;
-    *own_lo = h_lo;
-    *own_hi = h_lo + (ghi - glo);
-    const int N = (G.c - 1) * (1 << level) + 1;
-    *plane_elems = (long long)mg3d_pitch_for(N) * N;
-}
-
-/* the coarse planes of the first replicated level (ld-1) that rank r restricts into: those under its owned fine planes */
-static void plan_coarse_range(const PlanGeom &G, int r, int *lo, int *hi)
-{
-    int flo = 0, fhi = 0;
-    mg3d_slab_owned(G.c, G.L, G.P, G.H, G.ld, r, &flo, &fhi);
-    const int Nc = ((G.c - 1) << (G.ld - 1)) + 1;
-    *lo = r == 0 ? 0 : flo / 2;
-    *hi = r == G.P - 1 ? Nc : fhi / 2;
-}
-
-/* Halo planes skip+1 .. H (counted from the slab's owned planes) of `field` on distributed level l from the neighbours'
- * owned planes; skip = 0 is the whole halo.  Halo plane t of the upper side is the upper neighbour's t-th owned plane, of
- * the lower side the lower neighbour's t-th from the top. */
-static void plan_halo(Plan &pl, const PlanGeom &G, int kind, int field, int level, int rank, int skip, int stream)
-{
-    const int phase = (int)pl.kind.size();
-    pl.begin.push_back((int)pl.e.size());
-    pl.kind.push_back(kind);
-    pl.level.push_back(level);
-    const int n = G.H - skip;
-    if (n <= 0)
-        return;
-    int lo, hi;
-    long long pe;
-    slab_local(G, level, rank, &lo, &hi, &pe);
-    if (rank + 1 < G.P) {
-        pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_SEND, rank + 1, field, level, hi - G.H, n, pe, stream});
-        pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_RECV, rank + 1, field, level, hi + skip, n, pe, stream});
-    }
-    if (rank > 0) {
-        pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_SEND, rank - 1, field, level, lo + skip, n, pe, stream});
-        pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_RECV, rank - 1, field, level, lo - G.H, n, pe, stream});
-    }
-}
-
 static int build_plan(Plan &pl, int c, int L, int P, int nu, int rank, int overlap, int policy)
 {
     if (c < 3 || L < 2 || nu < 1 || P < 1 || rank < 0 || rank >= P)
         return MG3D_ERR_ARG;
-    PlanGeom G{c, L, P, nu, mg3d_slab_halo(nu), 0};
+    PlanGeom G{c, L, P, nu, mg3d_slab_halo(nu), 0, 16};
     G.ld = mg3d_slab_first_level(c, L, P, G.H);
     if (G.ld >= L)
         return MG3D_ERR_ARG;
     pl = Plan();
     const int lc = G.ld - 1, Nc = ((c - 1) << lc) + 1;
-    const long long pec = (long long)mg3d_pitch_for(Nc) * Nc;
+    const long long pec = plan_plane_elems(G, Nc);
     const int cs = overlap ? 1 : 0;
-    auto open_phase = [&](int kind, int level) {
-        pl.begin.push_back((int)pl.e.size());
-        pl.kind.push_back(kind);
-        pl.level.push_back(level);
-        return (int)pl.kind.size() - 1;
-    };
     for (int l = L - 1; l >= G.ld; l--) { /* down */
         plan_halo(pl, G, MG3D_XK_HALO_U_DOWN, MG3D_U, l, rank, 0, cs);
         if (l - 1 >= G.ld) {
             plan_halo(pl, G, MG3D_XK_HALO_D, MG3D_D, l - 1, rank, 0, 0);
         } else if (policy & 1) {
-            const int ph = open_phase(MG3D_XK_RHS_GATHER, lc);
+            const int ph = plan_open_phase(pl, MG3D_XK_RHS_GATHER, lc);
             for (int r = 1; r < P; r++) {
                 int lo, hi;
                 plan_coarse_range(G, r, &lo, &hi);
@@ -197,19 +136,12 @@ static int build_plan(Plan &pl, int c, int L, int P, int nu, int rank, int overl
                 if (rank == 0)
                     pl.e.push_back(mg3d_xfer{ph, MG3D_XK_RHS_GATHER, MG3D_XOP_RECV, r, MG3D_D, lc, lo, hi - lo, pec, 0});
             }
-        } else if (P > 1) {
-            const int ph = open_phase(MG3D_XK_RHS_ALLGATHER, lc);
-            for (int root = 0; root < P; root++) {
-                int lo, hi;
-                plan_coarse_range(G, root, &lo, &hi);
-                pl.e.push_back(mg3d_xfer{ph, MG3D_XK_RHS_ALLGATHER, MG3D_XOP_BCAST, root, MG3D_D, lc, lo, hi - lo, pec, 0});
-            }
         } else {
-            open_phase(MG3D_XK_RHS_ALLGATHER, lc);
+            plan_rhs_allgather(pl, G);
         }
     }
     if (policy & 1) {
-        const int ph = open_phase(MG3D_XK_CORR_BCAST, lc);
+        const int ph = plan_open_phase(pl, MG3D_XK_CORR_BCAST, lc);
         if (P > 1)
             pl.e.push_back(mg3d_xfer{ph, MG3D_XK_CORR_BCAST, MG3D_XOP_BCAST, 0, MG3D_U, lc, 0, Nc, pec, 0});
     }
@@ -219,11 +151,7 @@ static int build_plan(Plan &pl, int c, int L, int P, int nu, int rank, int overl
         if (l == L - 1)
             plan_halo(pl, G, MG3D_XK_HALO_U_NEXT, MG3D_U, l, rank, 1, cs);
     }
-    {
-        const int ph = open_phase(MG3D_XK_NORM, L - 1);
-        if (P > 1)
-            pl.e.push_back(mg3d_xfer{ph, MG3D_XK_NORM, MG3D_XOP_ALLGATHER, -1, -1, L - 1, rank, 1, 1, 0});
-    }
+    plan_norm(pl, G, L - 1, rank);
     pl.begin.push_back((int)pl.e.size());
     return MG3D_OK;
 }
@@ -756,62 +684,9 @@ static int run_phase(mg3d_dist *D, int kind, int level, hipStream_t s)
         RankState &R = D->rs[ri];
         return e.level >= D->ld ? SL(D, R, e.level).lv.f[e.field] : R.coarse->lv[e.level].f[e.field];
     };
-    if (D->loopback) {
-        for (size_t ri = 0; ri < D->plans.size(); ri++) {
-            const Plan &pl = D->plans[ri];
-            for (int i = pl.begin[(size_t)ph]; i < pl.begin[(size_t)ph + 1]; i++) {
-                const mg3d_xfer &e = pl.e[(size_t)i];
-                if (e.op == MG3D_XOP_SEND) {
-                    const Plan &pp = D->plans[(size_t)e.peer];
-                    const mg3d_xfer *m = nullptr;
-                    for (int k = pp.begin[(size_t)ph]; k < pp.begin[(size_t)ph + 1]; k++) {
-                        const mg3d_xfer &c = pp.e[(size_t)k];
-                        if (c.op == MG3D_XOP_RECV && c.peer == D->rs[ri].rank && c.field == e.field && c.level == e.level) {
-                            if (m)
-                                return fail(MG3D_ERR_STATE, "exchange plan: two receives match one send (phase %d)", ph);
-                            m = &c;
-                        }
-                    }
-                    if (!m || m->count != e.count || m->plane_elems != e.plane_elems)
-                        return fail(MG3D_ERR_STATE, "exchange plan: send of rank %d to %d in phase %d has no receive of its size",
-                                    D->rs[ri].rank, e.peer, ph);
-                    HIPCHK(hipMemcpyAsync(base((size_t)e.peer, *m) + m->plane_elems * m->offset, base(ri, e) + e.plane_elems * e.offset,
-                                          (size_t)e.count * e.plane_elems * sizeof(double), hipMemcpyDeviceToDevice, s));
-                } else if (e.op == MG3D_XOP_BCAST && D->rs[ri].rank == e.peer) {
-                    for (size_t dst = 0; dst < D->plans.size(); dst++)
-                        if (dst != ri)
-                            HIPCHK(hipMemcpyAsync(base(dst, e) + e.plane_elems * e.offset, base(ri, e) + e.plane_elems * e.offset,
-                                                  (size_t)e.count * e.plane_elems * sizeof(double), hipMemcpyDeviceToDevice, s));
-                } else if (e.op == MG3D_XOP_ALLGATHER && ri == 0) {
-                    RankState &R0 = D->rs[0];
-                    for (int r = 0; r < D->P; r++)
-                        HIPCHK(hipMemcpyAsync(R0.gather + r, D->rs[(size_t)r].coarse->sumsq, sizeof(double), hipMemcpyDeviceToDevice, s));
-                }
-            }
-        }
-        return MG3D_OK;
-    }
-    const Plan &pl = D->plans[0];
-    RankState &R = D->rs[0];
+    auto sumsq = [&](size_t ri) -> double * { return D->rs[ri].coarse->sumsq; };
     ncclComm_t comm = (s == D->comm_stream && D->have_comm2) ? D->comm2 : D->comm;
-    NCCLCHK(ncclGroupStart());
-    for (int i = pl.begin[(size_t)ph]; i < pl.begin[(size_t)ph + 1]; i++) {
-        const mg3d_xfer &e = pl.e[(size_t)i];
-        const size_t cnt = (size_t)e.count * e.plane_elems;
-        if (e.op == MG3D_XOP_ALLGATHER) {
-            NCCLCHK(ncclAllGather(R.coarse->sumsq, R.gather, cnt, ncclDouble, comm, s));
-            continue;
-        }
-        double *p = base(0, e) + e.plane_elems * e.offset;
-        if (e.op == MG3D_XOP_SEND)
-            NCCLCHK(ncclSend(p, cnt, ncclDouble, e.peer, comm, s));
-        else if (e.op == MG3D_XOP_RECV)
-            NCCLCHK(ncclRecv(p, cnt, ncclDouble, e.peer, comm, s));
-        else
-            NCCLCHK(ncclBroadcast(p, p, cnt, ncclDouble, e.peer, comm, s));
-    }
-    NCCLCHK(ncclGroupEnd());
-    return MG3D_OK;
+    return plan_run<double>(D->plans, ph, D->loopback, comm, ncclDouble, s, base, sumsq, D->rs[0].gather);
 }
 
 /* Start refreshing the u halos of level l behind everything queued on the compute stream so far, without

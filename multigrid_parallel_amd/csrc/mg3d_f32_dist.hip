@@ -30,6 +30,8 @@
 
 #include <rccl/rccl.h>
 
+#include "mg3d_plan.h"
+
 #define fail mg3d_fail
 #define HIPCHK(call)                                                                                    \
     do {                                                                                                \
@@ -63,7 +65,55 @@ struct mg3d32_dist {
     std::vector<int> rank_of;       /* their global rank numbers */
     double *gather, *d_norms, *h_norms;
     int norm_slots;
+    /* the exchange plans of one V-cycle from level q, with / without the norm phase, per local rank (mg3d32_dist_plan):
+     * plans[(q - ld) * 2 + want_norm][local rank]; the transports execute them entry by entry */
+    std::vector<std::vector<Plan>> plans;
+    const std::vector<Plan> *cur; /* the cycle being enqueued */
+    int phase;
 };
+
+/* One V-cycle from distributed level q (mg3d32_dist_plan, include/mg3d.h): u_q halos first (they were last refreshed
+ * before its owned planes changed), then per level u for the way up and the coarser right-hand side, the correction's
+ * halos on the way up, the norm.  Host arithmetic only. */
+static int build_plan32(Plan &pl, int c, int L, int P, int nu, int rank, int q, int want_norm)
+{
+    if (c < 3 || L < 2 || nu < 1 || P < 1 || rank < 0 || rank >= P || q >= L)
+        return MG3D_ERR_ARG;
+    PlanGeom G{c, L, P, nu, mg3d32_slab_halo(nu), 0, 32};
+    G.ld = mg3d_slab_first_level(c, L, P, G.H);
+    if (G.ld >= L || q < G.ld)
+        return MG3D_ERR_ARG;
+    pl = Plan();
+    plan_halo(pl, G, MG3D_XK_HALO_U_NEXT, MG3D_U, q, rank, 0, 0);
+    for (int l = q; l >= G.ld; l--) {
+        plan_halo(pl, G, MG3D_XK_HALO_U_DOWN, MG3D_U, l, rank, 0, 0);
+        if (l - 1 >= G.ld)
+            plan_halo(pl, G, MG3D_XK_HALO_D, MG3D_D, l - 1, rank, 0, 0);
+        else
+            plan_rhs_allgather(pl, G);
+    }
+    for (int l = G.ld + 1; l <= q; l++)
+        plan_halo(pl, G, MG3D_XK_HALO_U_UP, MG3D_U, l - 1, rank, 0, 0);
+    if (want_norm)
+        plan_norm(pl, G, q, rank);
+    pl.begin.push_back((int)pl.e.size());
+    return MG3D_OK;
+}
+
+/* the fp32 variant's plan: the V-cycle from level q (the F-cycle start runs them from every level); want_norm = 0
+ * leaves the norm phase out (cycles inside the F-cycle start) */
+extern "C" int mg3d32_dist_plan(int coarse_pts, int num_levels, int nranks, int smooth_iters, int rank, int q, int want_norm,
+                                mg3d_xfer *out, int max_entries)
+{
+    Plan pl;
+    const int rc = build_plan32(pl, coarse_pts, num_levels, nranks, smooth_iters, rank, q, want_norm);
+    if (rc != MG3D_OK)
+        return -rc;
+    if (out)
+        for (int i = 0; i < (int)pl.e.size() && i < max_entries; i++)
+            out[i] = pl.e[(size_t)i];
+    return (int)pl.e.size();
+}
 
 extern "C" int mg3d32_slab_halo(int smooth_iters) { return smooth_iters + 2; }
 
@@ -167,6 +217,21 @@ extern "C" int mg3d32_dist_create(int coarse_pts, int num_levels, int smooth_ite
         }
         D->have_comm = true;
     }
+    D->cur = nullptr;
+    D->phase = 0;
+    D->plans.resize((size_t)(num_levels - D->ld) * 2);
+    for (int q = D->ld; q < num_levels; q++)
+        for (int wn = 0; wn < 2; wn++) {
+            std::vector<Plan> &v = D->plans[(size_t)(q - D->ld) * 2 + wn];
+            v.resize(D->rs.size());
+            for (size_t ri = 0; ri < D->rs.size(); ri++) {
+                const int rc = build_plan32(v[ri], coarse_pts, num_levels, nranks, smooth_iters, D->rank_of[ri], q, wn);
+                if (rc != MG3D_OK) {
+                    mg3d32_dist_destroy(D);
+                    return fail(rc, "mg3d32_dist_create: no exchange plan for rank %d of %d", D->rank_of[ri], nranks);
+                }
+            }
+        }
     *out = D;
     return MG3D_OK;
 }
@@ -254,40 +319,25 @@ extern "C" int mg3d32_dist_sync(mg3d32_dist *D)
 }
 
 /* --------------------------------------------------------------------------------------- transport */
-/* all H halo planes of `field` on distributed level l from the neighbours' owned planes */
-static int exchange32(mg3d32_dist *D, int field, int l)
+/* the next phase of the plan of the cycle being enqueued (mg3d_plan.h: plan_run); kind / level say where the schedule
+ * believes it is */
+static int run_phase32(mg3d32_dist *D, int kind, int level)
 {
-    const int H = D->H;
-    hipStream_t s = D->stream;
+    const int ph = D->phase++;
+    for (const Plan &pl : *D->cur)
+        if (ph >= (int)pl.kind.size() || pl.kind[(size_t)ph] != kind || pl.level[(size_t)ph] != level)
+            return fail(MG3D_ERR_STATE, "fp32 slab schedule and exchange plan out of step at phase %d (schedule: kind %d level %d)",
+                        ph, kind, level);
     if (D->P == 1)
         return MG3D_OK;
-    if (D->loopback) {
-        for (int r = 0; r + 1 < D->P; r++) {
-            Level32 &a = D->rs[r]->lv[l], &b = D->rs[r + 1]->lv[l];
-            const size_t bytes = (size_t)H * a.g.plane * sizeof(float);
-            /* r's upper halo <- first owned planes of r+1 ; (r+1)'s lower halo <- last owned planes of r */
-            HIPCHK(hipMemcpyAsync(a.f[field] + a.g.plane * a.own_hi, b.f[field] + b.g.plane * b.own_lo, bytes,
-                                  hipMemcpyDeviceToDevice, s));
-            HIPCHK(hipMemcpyAsync(b.f[field] + b.g.plane * (b.own_lo - H), a.f[field] + a.g.plane * (a.own_hi - H), bytes,
-                                  hipMemcpyDeviceToDevice, s));
-        }
-        return MG3D_OK;
+    if (kind == MG3D_XK_NORM) { /* one double per rank: the all-gather is in doubles whatever the grid's precision */
+        auto none = [&](size_t, const mg3d_xfer &) -> double * { return nullptr; };
+        auto sumsq = [&](size_t ri) -> double * { return D->rs[ri]->sumsq; };
+        return plan_run<double>(*D->cur, ph, D->loopback, D->comm, ncclDouble, D->stream, none, sumsq, D->gather);
     }
-    Level32 &a = D->rs[0]->lv[l];
-    const int rank = D->rank_of[0];
-    const size_t cnt = (size_t)H * a.g.plane;
-    float *f = a.f[field];
-    NCCLCHK(ncclGroupStart());
-    if (rank + 1 < D->P) {
-        NCCLCHK(ncclSend(f + a.g.plane * (a.own_hi - H), cnt, ncclFloat, rank + 1, D->comm, s));
-        NCCLCHK(ncclRecv(f + a.g.plane * a.own_hi, cnt, ncclFloat, rank + 1, D->comm, s));
-    }
-    if (rank > 0) {
-        NCCLCHK(ncclSend(f + a.g.plane * a.own_lo, cnt, ncclFloat, rank - 1, D->comm, s));
-        NCCLCHK(ncclRecv(f + a.g.plane * (a.own_lo - H), cnt, ncclFloat, rank - 1, D->comm, s));
-    }
-    NCCLCHK(ncclGroupEnd());
-    return MG3D_OK;
+    auto base = [&](size_t ri, const mg3d_xfer &e) -> float * { return D->rs[ri]->lv[e.level].f[e.field]; };
+    auto sumsq = [&](size_t ri) -> double * { return D->rs[ri]->sumsq; };
+    return plan_run<float>(*D->cur, ph, D->loopback, D->comm, ncclFloat, D->stream, base, sumsq, D->gather);
 }
 
 /* the coarse planes of the first replicated level (ld-1) that rank r restricts into: those under its owned fine planes */
@@ -300,49 +350,13 @@ static void coarse_range(const mg3d32_dist *D, int r, int *lo, int *hi)
     *hi = r == D->P - 1 ? Nc : fhi / 2;
 }
 
-/* every rank ends up with the complete d of the first replicated level */
-static int allgather_coarse_rhs32(mg3d32_dist *D)
-{
-    hipStream_t s = D->stream;
-    const int lc = D->ld - 1;
-    if (D->P == 1)
-        return MG3D_OK;
-    if (D->loopback) {
-        for (int src = 0; src < D->P; src++) {
-            int lo, hi;
-            coarse_range(D, src, &lo, &hi);
-            const Level32 &ls = D->rs[src]->lv[lc];
-            const size_t bytes = (size_t)(hi - lo) * ls.g.plane * sizeof(float);
-            for (int dst = 0; dst < D->P; dst++)
-                if (dst != src)
-                    HIPCHK(hipMemcpyAsync(D->rs[dst]->lv[lc].f[MG3D_D] + ls.g.plane * lo, ls.f[MG3D_D] + ls.g.plane * lo,
-                                          bytes, hipMemcpyDeviceToDevice, s));
-        }
-        return MG3D_OK;
-    }
-    Level32 &l = D->rs[0]->lv[lc];
-    float *buf = l.f[MG3D_D];
-    NCCLCHK(ncclGroupStart());
-    for (int root = 0; root < D->P; root++) {
-        int lo, hi;
-        coarse_range(D, root, &lo, &hi);
-        NCCLCHK(ncclBroadcast(buf + l.g.plane * lo, buf + l.g.plane * lo, (size_t)(hi - lo) * l.g.plane, ncclFloat, root,
-                              D->comm, s));
-    }
-    NCCLCHK(ncclGroupEnd());
-    return MG3D_OK;
-}
-
 /* total = sum over ranks, in rank order (the same bits on every rank), of each rank's sumsq[0] */
-static int reduce_norm32(mg3d32_dist *D, int slot)
+static int reduce_norm32(mg3d32_dist *D, int q, int slot)
 {
     hipStream_t s = D->stream;
-    if (D->loopback || !D->have_comm) {
-        for (size_t r = 0; r < D->rs.size(); r++)
-            HIPCHK(hipMemcpyAsync(D->gather + r, D->rs[r]->sumsq, sizeof(double), hipMemcpyDeviceToDevice, s));
-    } else {
-        NCCLCHK(ncclAllGather(D->rs[0]->sumsq, D->gather, 1, ncclDouble, D->comm, s));
-    }
+    CHK(run_phase32(D, MG3D_XK_NORM, q));
+    if (D->P == 1)
+        HIPCHK(hipMemcpyAsync(D->gather, D->rs[0]->sumsq, sizeof(double), hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(sum32_in_order_kernel, dim3(1), dim3(64), 0, s, D->gather, D->P, D->d_norms + slot);
     return MG3D_OK;
 }
@@ -359,7 +373,9 @@ static int dist32_vcycle(mg3d32_dist *D, int q, int norm_slot)
             CHK(e32_vcycle(ctx, q, ctx->sumsq_slots - 1));
         return MG3D_OK;
     }
-    CHK(exchange32(D, MG3D_U, q));
+    D->cur = &D->plans[(size_t)(q - ld) * 2 + (norm_slot >= 0 ? 1 : 0)];
+    D->phase = 0;
+    CHK(run_phase32(D, MG3D_XK_HALO_U_NEXT, q));
     for (int l = q; l >= ld; l--) {
         for (size_t ri = 0; ri < D->rs.size(); ri++) {
             mg3d32_ctx *ctx = D->rs[ri];
@@ -374,17 +390,17 @@ static int dist32_vcycle(mg3d32_dist *D, int q, int norm_slot)
             Level32 &lc = ctx->lv[l - 1];
             HIPCHK(hipMemsetAsync(lc.f[MG3D_U], 0, lc.elems * sizeof(float), D->stream)); /* :1258 */
         }
-        CHK(exchange32(D, MG3D_U, l)); /* for the prolongation and the post-smoother on the way up */
+        CHK(run_phase32(D, MG3D_XK_HALO_U_DOWN, l)); /* for the prolongation and the post-smoother on the way up */
         if (l - 1 >= ld)
-            CHK(exchange32(D, MG3D_D, l - 1));
+            CHK(run_phase32(D, MG3D_XK_HALO_D, l - 1));
         else
-            CHK(allgather_coarse_rhs32(D));
+            CHK(run_phase32(D, MG3D_XK_RHS_ALLGATHER, ld - 1));
     }
     for (auto *ctx : D->rs)
         CHK(e32_vcycle(ctx, ld - 1, ctx->sumsq_slots - 1)); /* replicated levels and the direct solve */
     for (int l = ld; l <= q; l++) {
         if (l - 1 >= ld)
-            CHK(exchange32(D, MG3D_U, l - 1)); /* the correction's halos: prolongation covers every local fine plane */
+            CHK(run_phase32(D, MG3D_XK_HALO_U_UP, l - 1)); /* the correction's halos: prolongation covers every local fine plane */
         const bool top = l == q && norm_slot >= 0;
         for (auto *ctx : D->rs) {
             /* :1331 + :1341 (+ :1354): prolongation folded into the first paired sweep; the norm over the owned planes */
@@ -392,8 +408,11 @@ static int dist32_vcycle(mg3d32_dist *D, int q, int norm_slot)
                 e32_residual(ctx, l, false, 0);
         }
         if (top)
-            CHK(reduce_norm32(D, norm_slot));
+            CHK(reduce_norm32(D, q, norm_slot));
     }
+    if (D->phase != (int)(*D->cur)[0].kind.size())
+        return fail(MG3D_ERR_STATE, "fp32 slab schedule ended after %d of the plan's %d phases", D->phase,
+                    (int)(*D->cur)[0].kind.size());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(MG3D_ERR_HIP, "mg3d32_dist: kernel launch failed: %s", hipGetErrorString(e));
@@ -410,6 +429,12 @@ extern "C" int mg3d32_dist_vcycles(mg3d32_dist *D, int count, double *norms)
             CHK(dist32_vcycle(D, D->L - 1, c));
         HIPCHK(hipMemcpyAsync(D->h_norms, D->d_norms, nb * sizeof(double), hipMemcpyDeviceToHost, D->stream));
         HIPCHK(hipStreamSynchronize(D->stream));
+        if (D->have_comm) { /* an RCCL failure that surfaced asynchronously: an error here, not a wrong number later */
+            ncclResult_t ae = ncclSuccess;
+            NCCLCHK(ncclCommGetAsyncError(D->comm, &ae));
+            if (ae != ncclSuccess)
+                return fail(MG3D_ERR_HIP, "RCCL reported an asynchronous error: %s", ncclGetErrorString(ae));
+        }
         if (norms)
             for (int c = 0; c < nb; c++)
                 norms[done + c] = sqrt(D->h_norms[c]);
@@ -428,8 +453,18 @@ extern "C" int mg3d32_dist_fmg_initialize(mg3d32_dist *D)
         CHK(e32_coarse_solve(ctx));        /* :783 */
     }
     for (int l = 1; l < D->L; l++) {
-        if (l - 1 >= D->ld)
-            CHK(exchange32(D, MG3D_U, l - 1)); /* the interpolated solution is formed on every local plane */
+        if (l - 1 >= D->ld) { /* the interpolated solution is formed on every local plane: the halos of its parent */
+            std::vector<Plan> one(D->rs.size());
+            for (size_t ri = 0; ri < D->rs.size(); ri++) {
+                PlanGeom G{D->c, D->L, D->P, D->nu, D->H, D->ld, 32};
+                plan_halo(one[ri], G, MG3D_XK_HALO_U_UP, MG3D_U, l - 1, D->rank_of[ri], 0, 0);
+                one[ri].begin.push_back((int)one[ri].e.size());
+            }
+            D->cur = &one;
+            D->phase = 0;
+            CHK(run_phase32(D, MG3D_XK_HALO_U_UP, l - 1));
+            D->cur = nullptr;
+        }
         for (auto *ctx : D->rs) {
             e32_prolong(ctx, l);               /* :795 */
             e32_fill_boundary(ctx, MG3D_U, l); /* :798 */

@@ -20,12 +20,10 @@ E = namedtuple("E", "phase kind op peer field level offset count plane_elems str
 
 def entries(c, L, P, nu, rank, overlap=0, policy=0, fn="mg3d_dist_plan"):
     f = getattr(M.lib(), fn)
-    f.argtypes = [C.c_int] * 7 + [C.POINTER(Xfer), C.c_int]
-    f.restype = C.c_int
     n = f(c, L, P, nu, rank, overlap, policy, None, 0)
     assert n >= 0, f"{fn} failed: {n}"
     buf = (Xfer * max(n, 1))()
-    assert f(c, L, P, nu, rank, overlap, policy, buf, n) == n
+    assert f(c, L, P, nu, rank, overlap, policy, C.cast(buf, C.c_void_p), n) == n
     return [E(*(getattr(buf[i], k) for k in E._fields)) for i in range(n)]
 
 

@@ -131,7 +131,66 @@ def test_phase_sequence_of_a_cycle(c, L, nu, P):
 
 def test_plan_rejects_bad_arguments():
     f = M.lib().mg3d_dist_plan
-    f.restype = C.c_int
     assert f(9, 7, 8, 2, 8, 0, 0, None, 0) < 0   # rank out of range
     assert f(9, 7, 0, 2, 0, 0, 0, None, 0) < 0
     assert f(3, 3, 8, 2, 0, 0, 0, None, 0) < 0   # nothing can be distributed
+
+
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
+@pytest.mark.parametrize("c,L,nu", [(9, 8, 2), (9, 6, 2), (5, 6, 1), (3, 7, 3)])
+def test_fp32_variant_every_send_has_its_receive(c, L, nu, P):
+    """mg3d32_dist_plan (BASELINE configs[4]: fp32 / Jacobi on slabs, H = nu + 2, 32-float row pitch): the V-cycle from
+    every distributed level q -- the F-cycle start runs one from each -- with and without the norm phase.  The RCCL
+    branches of csrc/mg3d_f32_dist.hip issue exactly these entries; they have never run on two physical GPUs, so the
+    pairing of (own_hi - H, own_hi) with the upper neighbour's lower halo etc. is established here."""
+    lib = M.lib()
+    H = lib.mg3d32_slab_halo(nu)
+    assert H == nu + 2
+    ld = lib.mg3d_slab_first_level(c, L, P, H)
+    if ld >= L:
+        pytest.skip("no level gives every rank enough planes")
+    Nc = (c - 1) * (1 << (ld - 1)) + 1
+    for q in range(ld, L):
+        for want_norm in (0, 1):
+            plans = [PL.entries(c, L, P, nu, r, q, want_norm, fn="mg3d32_dist_plan") for r in range(P)]
+            nph = {max(e.phase for e in p) + 1 for p in plans}
+            assert len(nph) == 1
+            nph = nph.pop()
+            seq = []
+            for ph in range(nph):
+                per = [[e for e in p if e.phase == ph] for p in plans]
+                kinds = {(e.kind, e.level) for es in per for e in es}
+                assert len(kinds) == 1
+                seq.append(kinds.pop())
+                for r in range(P):
+                    for e in per[r]:
+                        assert e.stream == 0 and e.count > 0
+                        if e.op == PL.SEND:
+                            m = [x for x in per[e.peer] if x.op == PL.RECV and x.peer == r and x.field == e.field and x.level == e.level]
+                            assert len(m) == 1 and (m[0].count, m[0].plane_elems) == (e.count, e.plane_elems)
+                            a, b = slab(c, L, P, H, e.level, r), slab(c, L, P, H, e.level, e.peer)
+                            N = (c - 1) * (1 << e.level) + 1
+                            assert e.plane_elems == (N + 31) // 32 * 32 * N and e.count == H
+                            assert a["ig0"] + e.offset == b["ig0"] + m[0].offset
+                            assert a["own_lo"] <= e.offset and e.offset + e.count <= a["own_hi"]
+                            assert 0 <= m[0].offset and m[0].offset + m[0].count <= b["ni"]
+                            assert m[0].offset + m[0].count <= b["own_lo"] or m[0].offset >= b["own_hi"]
+                        elif e.op == PL.RECV:
+                            assert len([x for x in per[e.peer] if x.op == PL.SEND and x.peer == r and x.field == e.field and x.level == e.level]) == 1
+                if seq[-1][0] == PL.RHS_ALLGATHER:
+                    lists = [[(e.peer, e.offset, e.count) for e in es] for es in per]
+                    assert all(x == lists[0] for x in lists) and [x[0] for x in lists[0]] == list(range(P))
+                    cover = 0
+                    for root, off, cnt in lists[0]:
+                        flo, fhi = owned(c, L, P, H, ld, root)
+                        assert off == cover == (0 if root == 0 else flo // 2) and off + cnt == (Nc if root == P - 1 else fhi // 2)
+                        cover += cnt
+                    assert cover == Nc
+            want = [(PL.HALO_U_NEXT, q)]
+            for l in range(q, ld - 1, -1):
+                want.append((PL.HALO_U_DOWN, l))
+                want.append((PL.HALO_D, l - 1) if l - 1 >= ld else (PL.RHS_ALLGATHER, ld - 1))
+            want += [(PL.HALO_U_UP, l - 1) for l in range(ld + 1, q + 1)]
+            if want_norm:
+                want.append((PL.NORM, q))
+            assert seq == want
