@@ -283,7 +283,7 @@ def main():
     ap.add_argument("--cpu-port", action="store_true", help="time oracle/ (port) even if oracle/_ref exists")
     ap.add_argument("--cpu-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--breakdown", action="store_true", help="print the per-level stage table to stderr")
-    ap.add_argument("--timing-mode", type=int, default=3, help=argparse.SUPPRESS)  # A/B of the timer cost (0 = none)
+    ap.add_argument("--timing-mode", type=int, default=6, help=argparse.SUPPRESS)  # A/B of the timer cost (0 = none)
     ap.add_argument("--f32", action="store_true",
                     help="BASELINE configs[4] on one GPU instead of the headline: fp32, damped Jacobi, F-cycle start "
                          "(parity unpinned); default size 9 8 2 = 1025^3")
@@ -443,8 +443,9 @@ def main():
 
     warm_norms = solver.vcycles(args.warmup)
     solver.timing_reset()
-    # event pairs around the finest level's launches only (mode 3: 8 marker packets per cycle, ~5 us of idle queue each,
-    # no host stall).  --breakdown: every stage and kernel of every level
+    # event pairs around the finest level's launches only, on every 4th cycle of the timed region (mode 6 = 4 + 2: 8 marker
+    # packets per sampled cycle, ~5 us of idle queue each, no host stall; mode 3 = every cycle).  --breakdown: every stage
+    # and kernel of every level
     solver.timing_enable(1 if args.breakdown else args.timing_mode)
     barrier(solver)
     t0 = time.perf_counter()
@@ -523,8 +524,12 @@ def main():
             "finest_level_launches": launches_tab}
     if pmc_note:
         roof["traffic_note"] = pmc_note
-    finest_ms = sum(r["ms"] * r["launches"] for r in launches_tab) / max(1, args.steps)
-    finest_counter = sum(r["counter_bytes"] * r["launches"] for r in launches_tab if r["counter_bytes"]) / max(1, args.steps) \
+    # cycles of the timed region that carried the markers: all of them (--breakdown, mode 3) or every (mode - 2)-th
+    tmode = 1 if args.breakdown else args.timing_mode
+    sampled = args.steps if tmode < 4 else len(range(0, args.steps, tmode - 2))
+    roof["cycles_timed"] = sampled
+    finest_ms = sum(r["ms"] * r["launches"] for r in launches_tab) / max(1, sampled)
+    finest_counter = sum(r["counter_bytes"] * r["launches"] for r in launches_tab if r["counter_bytes"]) / max(1, sampled) \
         if launches_tab and all(r["counter_bytes"] is not None or not r["compulsory_bytes"] for r in launches_tab) else None
     roof["finest_level_ms_per_cycle"] = finest_ms
     # the metric's second half, "smoother HBM GB/s": always the pre-smoother's four-pass launch (compulsory bytes / time)

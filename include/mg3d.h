@@ -117,7 +117,8 @@ int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level);
 
 /* per-stage timers (timing_info.h:6-47), filled from hipEvent pairs recorded in-stream (no stall).
  * on: 0 = off, 1 = every level, 2 = finest level only, 3 = the kernel timers of the finest level only (no stage
- * timers: a third of the marker packets, what bench.py's roofline object needs). */
+ * timers: a third of the marker packets, what bench.py's roofline object needs), 4 + k = as 3 on every (k+2)-th full
+ * cycle only (a sample of the timed region: each marker costs ~5 us of idle queue). */
 int mg3d_timing_enable(mg3d_ctx *ctx, int on);
 int mg3d_timing_reset(mg3d_ctx *ctx);
 int mg3d_timing_get(mg3d_ctx *ctx, int level, int stage, int *num_calls, double *seconds);

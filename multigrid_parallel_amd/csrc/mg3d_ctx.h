@@ -43,7 +43,8 @@ struct mg3d_ctx {
     bool have_es;
     mg3d_es_params es;
     bool fused; /* fused sweep kernel (default) or one launch per colour pass (MG3D_NO_FUSE=1) */
-    int timing; /* 0 off, 1 every level, 2 finest level only, 3 finest level's kernel timers only */
+    int timing; /* 0 off, 1 every level, 2 finest level only, 3 finest level's kernel timers only, 4 + k: 3 on every (k+2)-th cycle */
+    int timing_phase; /* cycles since the last sampled one (timing >= 4) */
     std::vector<StageTimer> timers; /* [L][MG3D_NUM_STAGES] */
     /* stage timing never stalls the stream: event pairs are recorded in-stream and
      * resolved at the next host synchronisation the entry point does anyway */

@@ -110,7 +110,8 @@ static void resolve_timers(mg3d_ctx *ctx)
 /* scoped event pair: a stage of the reference's timing table, or (kernel = true) one kernel launch.
  * timing: 1 every level, 2 the finest level, 3 the finest level's kernel scopes only (what bench.py's roofline needs: 8
  * marker packets per cycle instead of 24; each costs ~5 us of idle queue, 0.09 against 0.04 ms of a 3.3 ms cycle.  Binding
- * the pair to the dispatch itself, hipExtLaunchKernelGGL, measured the same 0.04 ms as the 8 markers: not kept). */
+ * the pair to the dispatch itself, hipExtLaunchKernelGGL, measured the same 0.04 ms as the 8 markers: not kept), 4 + k
+ * (k >= 0): as 3, but only every (k + 2)-th full cycle carries the markers (a sample of the timed region). */
 struct StageScope {
     mg3d_ctx *ctx;
     mg3d_ctx::Pending p;
@@ -119,7 +120,8 @@ struct StageScope {
     {
         p.slot = kernel ? c->L * MG3D_NUM_STAGES + l * MG3D_NUM_KERNELS + s : l * MG3D_NUM_STAGES + s;
         p.a = p.b = nullptr;
-        on = ctx->timing == 1 || (ctx->timing == 2 && l == ctx->L - 1) || (ctx->timing == 3 && kernel && l == ctx->L - 1);
+        on = ctx->timing == 1 || (ctx->timing == 2 && l == ctx->L - 1) ||
+             (ctx->timing >= 3 && kernel && l == ctx->L - 1 && ctx->timing_phase == 0);
         if (on && (p.a = take_event(ctx)))
             (void)hipEventRecord(p.a, ctx->stream);
     }
@@ -200,6 +202,7 @@ static mg3d_ctx *ctx_new(int L, int iters)
     ctx->stream = nullptr;
     ctx->own_stream = true;
     ctx->timing = 0;
+    ctx->timing_phase = 0;
     ctx->timers.assign((size_t)L * (MG3D_NUM_STAGES + MG3D_NUM_KERNELS), StageTimer{0, 0.});
     ctx->lv.resize(L);
     for (auto &l : ctx->lv)
@@ -792,11 +795,36 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
                                     "(mg3d_es_vcycles, or load the Dirichlet factor again)");
     hipStream_t s = ctx->stream;
     const int L = ctx->L;
+    struct PhaseTick { /* sampled kernel timers (timing >= 4): full cycles are counted off, also on an early return */
+        mg3d_ctx *c;
+        bool full;
+        ~PhaseTick()
+        {
+            if (full && c->timing >= 4)
+                c->timing_phase = (c->timing_phase + 1) % (c->timing - 2);
+        }
+    } tick{ctx, q == L - 1};
     /* level 1 below the top of the cycle, small enough for one workgroup's LDS: two launches instead of five */
     const bool no_tiny = getenv("MG3D_NO_TINY") && getenv("MG3D_NO_TINY")[0] == '1'; /* read per cycle: tests toggle it */
     const bool tiny = !no_tiny && ctx->fused && !ctx->keep_r && q >= 2 && ctx->iters >= 1 && k_tiny_fits(ctx->lv[1].g, ctx->lv[0].g);
+    /* ... and the whole bottom of the cycle (level 1 down, the direct solve, level 1 up) as ONE launch when the reduced
+     * factor exists (mg3d_tiny.hip, tiny_cycle_kernel); MG3D_NO_TINY_CYCLE=1 keeps the three launches (tests compare) */
+    const bool no_cyc = getenv("MG3D_NO_TINY_CYCLE") && getenv("MG3D_NO_TINY_CYCLE")[0] == '1';
+    const bool tiny_cyc = tiny && !no_cyc && k_tiny_cycle_fits(ctx->lv[1].g, ctx->lv[0].g, ctx->lu, ctx->lu_in);
     for (int l = q; l >= 1; l--) {
         Level &lev = ctx->lv[l];
+        if (l == 1 && tiny_cyc) {
+            {
+                StageScope t(ctx, l, MG3D_ST_SMOOTH1);
+                StageScope kt(ctx, l, MG3D_K_SWEEP4, true);
+                k_tiny_cycle(lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.f[MG3D_R], ctx->lv[0].g, ctx->lv[0].f[MG3D_D],
+                             ctx->lv[0].f[MG3D_U], ctx->lu, ctx->lu_in, lev.h, ctx->iters, s); /* :1258 ... :1341 of levels 1, 0 */
+            }
+            { StageScope t(ctx, l, MG3D_ST_RESIDUAL1); } /* inside the launch above: counted, ~0 s */
+            { StageScope t(ctx, l, MG3D_ST_RESTRICT); }
+            ctx->faces_dirty[l] = 0;
+            continue;
+        }
         if (l == 1 && tiny) {
             {
                 StageScope t(ctx, l, MG3D_ST_SMOOTH1);
@@ -842,7 +870,9 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
             }
         }
     }
-    {
+    if (tiny_cyc) {
+        StageScope t(ctx, 0, MG3D_ST_RECURSE); /* inside the launch above */
+    } else {
         Level &l0 = ctx->lv[0];
         if (0 < L - 1)
             (void)hipMemsetAsync(l0.f[MG3D_U], 0, l0.elems * sizeof(double), s);
@@ -852,6 +882,12 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
     }
     for (int l = 1; l <= q; l++) {
         Level &lev = ctx->lv[l];
+        if (l == 1 && tiny_cyc) {
+            { StageScope t(ctx, l, MG3D_ST_PROLONG); }
+            { StageScope t(ctx, l, MG3D_ST_SMOOTH2); }
+            { StageScope t(ctx, l, MG3D_ST_RESIDUAL2); }
+            continue;
+        }
         if (l == 1 && tiny) {
             { StageScope t(ctx, l, MG3D_ST_PROLONG); } /* inside the launch below */
             {
@@ -972,7 +1008,8 @@ extern "C" int mg3d_timing_enable(mg3d_ctx *ctx, int on)
 {
     if (!ctx)
         return fail(MG3D_ERR_ARG, "mg3d_timing_enable: NULL context");
-    ctx->timing = (on >= 1 && on <= 3) ? on : 0;
+    ctx->timing = (on >= 1 && on <= 64) ? on : 0;
+    ctx->timing_phase = 0;
     return MG3D_OK;
 }
 

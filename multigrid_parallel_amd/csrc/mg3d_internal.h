@@ -86,6 +86,11 @@ void k_tiny_down(const Geom &g, double *u, const double *d, const double *r, con
                  hipStream_t s);
 /* u += P(ec) at every point, then `iters` x (black, red) */
 void k_tiny_up(const Geom &g, double *u, const double *d, const Geom &gc, const double *ec, double h, int iters, hipStream_t s);
+/* the bottom of the cycle in one launch: tiny_down on level 1, the direct solve of level 0 (reduced factor lin, the full
+ * one as its fall-back), tiny_up on level 1; dc / xc receive level 0's right-hand side and solution */
+bool k_tiny_cycle_fits(const Geom &g, const Geom &gc, const LuBand &lu, const LuBand &lin);
+void k_tiny_cycle(const Geom &g, double *u, const double *d, const double *r, const Geom &gc, double *dc, double *xc,
+                  const LuBand &lu, const LuBand &lin, double h, int iters, hipStream_t s);
 /* b and x are level-0 grids in the padded layout g0; work holds 2n doubles */
 /* steps per chunk of the streamed solve for n unknowns and rot_r = R on the current device, 0 if it cannot run */
 int mg3d_lu_stream_chunk(int n, int R);

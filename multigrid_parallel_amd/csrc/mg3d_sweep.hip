@@ -906,23 +906,23 @@ template <> int dispatch<4, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
 template <> int dispatch<4, 0>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(4, 0, 8, 4, 1) TRY(4, 0, 6, 4, 2) TRY(4, 0, 6, 4, 3) TRY(4, 0, 4, 8, 1) TRY(4, 0, 4, 8, 2)
-    TRY(4, 0, 2, 8, 2) TRY(4, 0, 2, 8, 4)
+    TRY(4, 0, 2, 8, 2) TRY(4, 0, 2, 8, 4) TRY(4, 0, 2, 16, 1)
     DFLT(4, 0, 4, 8, 1)
 }
 template <> int dispatch<2, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
-    TRY(2, 1, 4, 8, 1) TRY(2, 1, 8, 4, 2) TRY(2, 1, 6, 4, 2)
+    TRY(2, 1, 4, 8, 1) TRY(2, 1, 8, 4, 2) TRY(2, 1, 6, 4, 2) TRY(2, 1, 2, 16, 1)
     DFLT(2, 1, 4, 8, 1)
 }
 template <> int dispatch<2, 0>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(2, 0, 6, 8, 1) TRY(2, 0, 8, 4, 2) TRY(2, 0, 4, 8, 1) TRY(2, 0, 4, 8, 2) TRY(2, 0, 4, 8, 3)
-    TRY(2, 0, 2, 8, 4)
+    TRY(2, 0, 2, 8, 4) TRY(2, 0, 2, 16, 1)
     DFLT(2, 0, 4, 8, 1)
 }
 template <> int dispatch<0, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
-    TRY(0, 1, 4, 8, 1) TRY(0, 1, 8, 4, 2) TRY(0, 1, 4, 8, 2) TRY(0, 1, 4, 8, 3) TRY(0, 1, 2, 8, 4)
+    TRY(0, 1, 4, 8, 1) TRY(0, 1, 8, 4, 2) TRY(0, 1, 4, 8, 2) TRY(0, 1, 4, 8, 3) TRY(0, 1, 2, 8, 4) TRY(0, 1, 2, 16, 1)
     DFLT(0, 1, 4, 8, 1)
 }
 
@@ -930,7 +930,7 @@ template <> int dispatch<0, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
  * partial sums written (0 when no norm was requested), -1 if the shape is unsupported. */
 template <> int dispatch<0, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
-    TRY(0, 2, 4, 8, 1) TRY(0, 2, 4, 8, 2) TRY(0, 2, 2, 8, 2) TRY(0, 2, 2, 8, 4)
+    TRY(0, 2, 4, 8, 1) TRY(0, 2, 4, 8, 2) TRY(0, 2, 2, 8, 2) TRY(0, 2, 2, 8, 4) TRY(0, 2, 2, 16, 1)
     DFLT(0, 2, 4, 8, 1)
 }
 template <> int dispatch<4, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)

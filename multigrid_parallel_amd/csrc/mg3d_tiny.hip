@@ -12,7 +12,9 @@
  * kernels (tests/test_gpu_parity.py compares both paths).
  */
 #include "mg3d_internal.h"
+#include "mg3d_lu_dev.h"
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -185,6 +187,227 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_up_kernel(Geom g, double *_
     }
 }
 
+/* ---- the whole bottom of the cycle in ONE workgroup: tiny_down, the direct solve of the coarsest level and tiny_up
+ * (mg_3d.h:1258-1310 on level 1, :1262-1277 on level 0, :1331-1341 on level 1).  Three dependent launches and a memset
+ * (19 + 5 + 33 + 20 us in the kernel trace, most of it launch and first-touch latency) become one: u and d of level 1
+ * stay in LDS across the solve, the coarse right-hand side never leaves the CU, the factors are streamed through the
+ * LDS ring of lu_stream_solve (mg3d_lu_dev.h) by two of the workgroup's waves exactly as in the stand-alone solve.
+ * The solve is the REDUCED one (install_lu, mg3d_ctx.hip: the factor without its identity rows) -- valid because the
+ * faces of the coarse right-hand side are the injected faces of r, zeros unless somebody wrote r from outside the cycle;
+ * if one of them is not a zero the full system is solved by the single-wave substitution with the factors read from
+ * global memory (slow, correct, never seen in a V-cycle).  Every expression and order is the one of the three kernels it
+ * replaces (tests compare both routes bit for bit: MG3D_NO_TINY_CYCLE=1).
+ * A thread keeps the LDS indices and colours of the (at most TINY_PTS) interior points it owns in registers: the integer
+ * divisions that decode them are paid once, not once per colour pass. */
+#define TINY_CYC_THREADS 512
+#define TINY_PTS 7 /* ceil(15^3 / 512) */
+
+template <int RF>
+__global__ void __launch_bounds__(TINY_CYC_THREADS) tiny_cycle_kernel(Geom g, double *__restrict__ u_io,
+                                                                    const double *__restrict__ d_in,
+                                                                    const double *__restrict__ r_in, Geom gc,
+                                                                    double *__restrict__ dc, double *__restrict__ xc,
+                                                                    LuBand lu, LuBand lin, double hSq, double sixth,
+                                                                    double invHsq, int iters, int s_doubles)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int N = g.N, n = N * N * N, Nc = gc.N, nc = Nc * Nc * Nc, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *u = lds, *d = lds + n, *S = lds + 2 * n, *ec = S + s_doubles;
+    double *r = S, *bfull = S + n; /* bfull: lu.npad entries */
+    /* the interior points this thread owns */
+    const int M = N - 2, m = M * M * M;
+    int pt[TINY_PTS], col[TINY_PTS];
+#pragma unroll
+    for (int q = 0; q < TINY_PTS; q++) {
+        const int t = tid + q * TINY_CYC_THREADS;
+        if (t < m) {
+            const int i = 1 + t / (M * M), j = 1 + (t / M) % M, k = 1 + t % M;
+            pt[q] = lidx(N, i, j, k);
+            col[q] = (i + j + k) & 1;
+        } else {
+            pt[q] = -1;
+            col[q] = -1;
+        }
+    }
+    auto pass = [&](int colour) { /* mg_3d.h:438-443, 658-702 */
+#pragma unroll
+        for (int q = 0; q < TINY_PTS; q++)
+            if (col[q] == colour) {
+                const int p = pt[q];
+                double s = u[p - N * N] + u[p + N * N];
+                s = s + u[p - N];
+                s = s + u[p + N];
+                s = s + u[p - 1];
+                s = s + u[p + 1];
+                s = s - hSq * d[p];
+                u[p] = sixth * s;
+            }
+        __syncthreads();
+    };
+    /* ---- down (tiny_down_kernel): zero guess, pre-smoothing, residual, restriction */
+    /* whole-field loops: thread (j, k) walks its column along i -- one integer division per thread and kernel instead of
+     * three per point and loop (a division by a run-time value costs ~35 instructions; decoding every point in every
+     * loop was half of this kernel's time) */
+    const bool has_col = tid < N * N, has_ccol = tid < Nc * Nc;
+    const int cj = tid / N, ck = tid - cj * N, ccj = tid / Nc, cck = tid - ccj * Nc;
+    const long long gcol = (long long)g.pitch * cj + ck, gccol = (long long)gc.pitch * ccj + cck;
+    if (has_col)
+        for (int i = 0; i < N; i++) {
+            u[i * N * N + tid] = 0.;
+            d[i * N * N + tid] = d_in[g.plane * i + gcol];
+        }
+    __syncthreads();
+    for (int s = 0; s < iters; s++) {
+        pass(1);
+        pass(0);
+    }
+#pragma unroll
+    for (int q = 0; q < TINY_PTS; q++)
+        if (pt[q] >= 0) { /* mg_3d.h:819-821 */
+            const int p = pt[q];
+            double s = u[p - N * N] + u[p + N * N];
+            s = s + u[p - N];
+            s = s + u[p + N];
+            s = s + u[p - 1];
+            s = s + u[p + 1];
+            s = s - 6 * u[p];
+            r[p] = d[p] - invHsq * s;
+        }
+    __syncthreads();
+    int nonzero = 0;
+    for (int t = nc + tid; t < lu.npad; t += TINY_CYC_THREADS)
+        bfull[t] = 0.; /* the padding rows of the factor */
+    if (has_ccol)
+        for (int ic = 0; ic < Nc; ic++) {
+            const int jc = ccj, kc = cck, t = ic * Nc * Nc + tid;
+            const bool face = ic == 0 || ic == Nc - 1 || jc == 0 || jc == Nc - 1 || kc == 0 || kc == Nc - 1;
+            double val = 0.;
+            if (face) { /* injection, mg_3d.h:879-958, from r's boundary entries as memory holds them */
+                val = r_in[g.plane * (2 * ic) + (long long)g.pitch * (2 * jc) + 2 * kc];
+                nonzero |= (__double_as_longlong(val) << 1) != 0ll;
+                ec[t] = val; /* an identity row of the coarse operator: x = (b - (+0)) / 1 = b */
+            } else {
+                const int pf = lidx(N, 2 * ic, 2 * jc, 2 * kc);
+#pragma unroll
+                for (int ti = -1; ti <= 1; ti++)
+#pragma unroll
+                    for (int tj = -1; tj <= 1; tj++)
+#pragma unroll
+                        for (int tk = -1; tk <= 1; tk++) {
+                            const double w = (ti ? 0.25 : 0.5) * (tj ? 0.25 : 0.5) * (tk ? 0.25 : 0.5);
+                            val += r[pf + ti * N * N + tj * N + tk] * w;
+                        }
+            }
+            dc[gc.plane * ic + gccol] = val;
+            bfull[t] = val;
+        }
+    const int bad = __syncthreads_or(nonzero); /* workgroup-uniform; also: bfull, ec faces are complete */
+    /* ---- the direct solve (gauss_elim.h:31-60) */
+    if (!bad) {
+        const int npi = lin.npad;
+        double *ring = S, *bi = S + 2 * 64 * 64, *zi = bi + npi, *dg = zi + npi;
+        for (int p = tid; p < npi; p += TINY_CYC_THREADS) {
+            bi[p] = 0.;
+            dg[p] = lin.diag[p];
+            dg[npi + p] = lin.diag[npi + p];
+        }
+        __syncthreads();
+        for (int p = tid; p < nc; p += TINY_CYC_THREADS) {
+            const int q = lu.in_map[p];
+            if (q >= 0)
+                bi[q] = bfull[p];
+        }
+        __syncthreads(); /* bfull lies where the ring is about to be filled */
+        lu_stream_solve<1>(lin, ring, bi, zi, dg, lane, wave);
+        for (int p = tid; p < nc; p += TINY_CYC_THREADS) {
+            const int q = lu.in_map[p];
+            if (q >= 0)
+                ec[p] = bi[q];
+        }
+    } else {
+        const int n0 = lu.n;
+        double *z = S, *dg = S + n0; /* r is dead; bfull (the right-hand side, then the solution) lies behind both */
+        for (int p = tid; p < n0; p += TINY_CYC_THREADS) {
+            dg[p] = lu.diag[p];
+            dg[n0 + p] = lu.diag[lu.npad + p];
+        }
+        __syncthreads();
+        if (wave == 0)
+            lu_wave_pass<RF, true, false>(lu, lane, bfull, z, dg);
+        __syncthreads();
+        if (wave == 0) {
+            if (lu.fast_div)
+                lu_wave_pass<RF, false, true>(lu, lane, z, bfull, dg);
+            else
+                lu_wave_pass<RF, false, false>(lu, lane, z, bfull, dg);
+        }
+        __syncthreads();
+        for (int p = tid; p < nc; p += TINY_CYC_THREADS)
+            ec[p] = bfull[p];
+    }
+    __syncthreads();
+    if (has_ccol)
+        for (int ic = 0; ic < Nc; ic++)
+            xc[gc.plane * ic + gccol] = ec[ic * Nc * Nc + tid];
+    /* ---- up (tiny_up_kernel): prolongation + correction at every fine point (mg_3d.h:1000-1145), post-smoothing */
+    const int sI = Nc * Nc, sJ = Nc, sK = 1;
+    for (int i = 0; has_col && i < N; i++) {
+        const int j = cj, k = ck, t = i * N * N + tid;
+        const int oi = i & 1, oj = j & 1, ok = k & 1;
+        const int c0 = (((i - oi) / 2) * Nc + (j - oj) / 2) * Nc + (k - ok) / 2;
+        double x = 0.;
+        switch (oi + oj + ok) {
+        case 3:
+            x += ec[c0];
+            x += ec[c0 + sK];
+            x += ec[c0 + sJ];
+            x += ec[c0 + sJ + sK];
+            x += ec[c0 + sI];
+            x += ec[c0 + sI + sK];
+            x += ec[c0 + sI + sJ];
+            x += ec[c0 + sI + sJ + sK];
+            x *= 0.125;
+            break;
+        case 2:
+            if (!oi) {
+                x += ec[c0];
+                x += ec[c0 + sJ];
+                x += ec[c0 + sK];
+                x += ec[c0 + sJ + sK];
+            } else if (!oj) {
+                x += ec[c0];
+                x += ec[c0 + sI];
+                x += ec[c0 + sK];
+                x += ec[c0 + sI + sK];
+            } else {
+                x += ec[c0];
+                x += ec[c0 + sJ];
+                x += ec[c0 + sI];
+                x += ec[c0 + sI + sJ];
+            }
+            x *= 0.25;
+            break;
+        case 1:
+            x += ec[c0];
+            x += ec[c0 + oi * sI + oj * sJ + ok * sK];
+            x *= 0.5;
+            break;
+        default:
+            x = ec[c0];
+        }
+        u[t] += x;
+    }
+    __syncthreads();
+    for (int s = 0; s < iters; s++) {
+        pass(0);
+        pass(1);
+    }
+    if (has_col)
+        for (int i = 0; i < N; i++)
+            u_io[g.plane * i + gcol] = u[i * N * N + tid];
+}
+
 /* Dynamic LDS above the 64 KB a kernel gets without asking (118 KB at 17^3) is granted per kernel AND per device: asked
  * for once per (kernel, device), the answer remembered; a refusal (or a device whose opt-in limit is too small) sends the
  * level through the generic kernels instead of failing at launch. */
@@ -237,4 +460,51 @@ void k_tiny_down(const Geom &g, double *u, const double *d, const double *r, con
 void k_tiny_up(const Geom &g, double *u, const double *d, const Geom &gc, const double *ec, double h, int iters, hipStream_t s)
 {
     hipLaunchKernelGGL(tiny_up_kernel, dim3(1), dim3(TINY_THREADS), tiny_up_lds(g, gc), s, g, u, d, gc, ec, h * h, 1. / 6, iters);
+}
+
+/* the S region of tiny_cycle_kernel in doubles: r and the full right-hand side, or the reduced solve's ring and vectors */
+static int tiny_cycle_s_doubles(const Geom &g, const LuBand &lu, const LuBand &lin)
+{
+    const int n = g.N * g.N * g.N;
+    const int a = n + lu.npad, b = 2 * 64 * 64 + 4 * lin.npad, c = 3 * lu.n;
+    return std::max(a, std::max(b, c));
+}
+
+static size_t tiny_cycle_lds(const Geom &g, const Geom &gc, const LuBand &lu, const LuBand &lin)
+{
+    return sizeof(double) * (2 * (size_t)g.N * g.N * g.N + (size_t)tiny_cycle_s_doubles(g, lu, lin) + (size_t)gc.N * gc.N * gc.N);
+}
+
+bool k_tiny_cycle_fits(const Geom &g, const Geom &gc, const LuBand &lu, const LuBand &lin)
+{
+    if (!k_tiny_fits(g, gc) || !lu.in_map || lin.n <= 0 || lin.rot_r != 1 || lin.stream_ch != 64 || !lin.stream)
+        return false;
+    if ((lu.rot_r != 1 && lu.rot_r != 2) || !lu.lrot || !lu.urot || lu.n != gc.N * gc.N * gc.N)
+        return false;
+    const int M = g.N - 2;
+    if (M * M * M > TINY_PTS * TINY_CYC_THREADS)
+        return false;
+    const size_t lds = tiny_cycle_lds(g, gc, lu, lin) + 512; /* + the workgroup vote's static bytes */
+    const void *k = lu.rot_r == 2 ? (const void *)tiny_cycle_kernel<2> : (const void *)tiny_cycle_kernel<1>;
+    int dev = 0, max_lds = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess)
+        return false;
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && optin > max_lds)
+        max_lds = optin;
+    return lds <= (size_t)max_lds && tiny_lds_granted(k, lds - 512);
+}
+
+void k_tiny_cycle(const Geom &g, double *u, const double *d, const double *r, const Geom &gc, double *dc, double *xc,
+                  const LuBand &lu, const LuBand &lin, double h, int iters, hipStream_t s)
+{
+    const size_t lds = tiny_cycle_lds(g, gc, lu, lin);
+    const int sd = tiny_cycle_s_doubles(g, lu, lin);
+    if (lu.rot_r == 2)
+        hipLaunchKernelGGL(tiny_cycle_kernel<2>, dim3(1), dim3(TINY_CYC_THREADS), lds, s, g, u, d, r, gc, dc, xc, lu, lin, h * h,
+                           1. / 6, 1. / (h * h), iters, sd);
+    else
+        hipLaunchKernelGGL(tiny_cycle_kernel<1>, dim3(1), dim3(TINY_CYC_THREADS), lds, s, g, u, d, r, gc, dc, xc, lu, lin, h * h,
+                           1. / 6, 1. / (h * h), iters, sd);
 }

@@ -628,6 +628,50 @@ def test_single_workgroup_level_equals_the_generic_kernels(monkeypatch, c, L, nu
     np.testing.assert_allclose(res[0][0], want_norms, rtol=norm_rtol((c - 1) * (1 << (L - 1)) + 1))
 
 
+@pytest.mark.parametrize("dirty_r", [False, True])
+@pytest.mark.parametrize("c,L,nu", [(9, 4, 2), (9, 3, 1), (5, 5, 2), (5, 3, 3), (3, 6, 2), (9, 5, 2)])
+def test_bottom_of_the_cycle_in_one_launch(monkeypatch, c, L, nu, dirty_r):
+    """Level 1 down, the direct solve on level 0 and level 1 up as ONE single-workgroup launch (tiny_cycle_kernel, with the
+    reduced factor inside) against the three launches it replaces (MG3D_NO_TINY_CYCLE=1) and the oracle: u and d of every
+    level.  dirty_r: non-zero values on the FACES of r on level 1, written from outside the cycle -- the restriction
+    injects them into the coarse right-hand side (mg_3d.h:879-958), the reduced system no longer applies and the launch
+    takes its full-system route (single-wave substitution); the reference sees exactly such values too."""
+    N1 = 2 * c - 1
+    rng = np.random.default_rng(c * 100 + L)
+    r1 = rng.uniform(-1, 1, (N1, N1, N1))
+    r1[1:-1, 1:-1, 1:-1] = 0.0
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MG3D_NO_TINY_CYCLE", flag)
+        with M.Solver(c, L, nu) as s:
+            s.setup_test_problem()
+            if dirty_r:
+                s.upload(MG3D_R, 1, r1.reshape(-1))
+            norms = s.vcycles(3)
+            res.append((norms, [s.download(MG3D_U, l) for l in range(L)], [s.download(MG3D_D, l) for l in range(L - 1)]))
+    assert np.array_equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert np.array_equal(a, b) and np.array_equal(np.signbit(a), np.signbit(b))
+    H = O.Hierarchy(c, L)
+    N, h = H.N[-1], 1.0 / (H.N[-1] - 1)
+    LU = np.zeros(c ** 6)
+    O.lib().orc_coarse_matrix(O.P(LU), c, h * (1 << (L - 1)))
+    O.lib().orc_lu_factor(O.P(LU), c ** 3)
+    O.lib().orc_fill_boundary(O.P(H.d[-1]), N, h)
+    O.lib().orc_fill_boundary(O.P(H.u[-1]), N, h)
+    if dirty_r:
+        H.r[1][:] = r1.reshape(-1)
+    O.lib().orc_set_threads(1)
+    want = [O.lib().orc_vcycle(H.ptrs(H.u), H.ptrs(H.d), H.ptrs(H.r), h, L - 1, L, nu, N, O.P(LU)) for _ in range(3)]
+    np.testing.assert_allclose(res[0][0], want, rtol=norm_rtol(N))
+    for l in range(L):
+        assert np.array_equal(res[0][1][l], H.u[l]), f"u level {l}"
+    for l in range(L - 1):
+        assert np.array_equal(res[0][2][l], H.d[l]), f"d level {l}"
+    if dirty_r:
+        assert np.any(H.d[0] != 0) and np.any(H.d[0].reshape(c, c, c)[0] != 0)  # the injected faces really are there
+
+
 @pytest.mark.parametrize("c,L", [(9, 4), (5, 5), (3, 6)])
 def test_one_sweep_down_leg_two_launches_equal_the_fused_shape(monkeypatch, c, L):
     """V(1,1): two colour passes + residual + restriction run as two launches by default (the one-launch shape spills
