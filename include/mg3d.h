@@ -122,6 +122,9 @@ int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level);
 int mg3d_timing_enable(mg3d_ctx *ctx, int on);
 int mg3d_timing_reset(mg3d_ctx *ctx);
 int mg3d_timing_get(mg3d_ctx *ctx, int level, int stage, int *num_calls, double *seconds);
+/* diagnostic: phase stamps (100 MHz clock) of the last single-workgroup coarse cycle launch (csrc/mg3d_tiny.hip):
+ * start, d loaded, pre-smoothed, residual, restricted, solve start, solve end, correction ready, prolonged, post-smoothed, stored */
+int mg3d_debug_tiny_stamps(long long *out16);
 /* per-kernel timers, same mechanism, one event pair around each launch of the kernels below */
 enum {
     MG3D_K_SWEEP4 = 0,   /* fused sweep, 4 colour passes */

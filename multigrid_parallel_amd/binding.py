@@ -82,6 +82,7 @@ SIGNATURES = {
     "mg3d_slab_first_level": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mg3d_slab_owned": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                   C.POINTER(C.c_int)]),
+    "mg3d_debug_tiny_stamps": (C.c_int, [C.POINTER(C.c_longlong)]),
     "mg3d_dist_plan": (C.c_int, [C.c_int] * 7 + [C.c_void_p, C.c_int]),
     "mg3d32_dist_plan": (C.c_int, [C.c_int] * 7 + [C.c_void_p, C.c_int]),
     "mg3d_dist_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),

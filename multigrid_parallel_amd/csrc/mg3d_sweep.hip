@@ -79,6 +79,8 @@ struct SweepArgs {
     double *dc;
     int ic_lo, ic_hi;
     int xcd_remap;  /* 1: blocks of one XCD group (blockIdx % 8) take consecutive shares of the work */
+    int rev;        /* 1: the i-chunks are handed out last to first (the launch before it ended on the last planes: what of
+                       them is still in the Infinity Cache is read first).  Speed only. */
 };
 
 /* RES: 0 = smoothing only, 1 = + residual (r store and/or norm), 2 = + residual AND full-weighting
@@ -202,7 +204,8 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     if (lockstep) {
         /* block -> (tile column, i-chunk), tile fastest: all tile columns of a chunk march through the same planes at
          * the same time, so a neighbour's halo rows are still in the Infinity Cache / L2 */
-        const int T = a.ntj * a.ntk, ch = vb / T;
+        const int T = a.ntj * a.ntk;
+        int ch = vb / T;
         int tl = vb - ch * T;
         if (a.xcd_remap == 2) {
             /* several rounds of blocks: inside every chunk's layer of T blocks, the blocks of one XCD group take a
@@ -217,6 +220,8 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
             tl = o + (tl - ((x - r0 + 8) & 7)) / 8;
         }
         t_lin = tl;
+        if (a.rev)
+            ch = (int)(gridDim.x / T) - 1 - ch;
         off = ch * a.CI;
         len = min(a.CI, nout - off);
     } else {
@@ -763,6 +768,11 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
                 forced = true;
             }
     a.snap = 0;
+    {
+        /* MG3D_SWEEP_REV: bit 0 the restricting launches, bit 1 the smoothing launches, bit 2 the residual-norm ones */
+        static const int rev_env = getenv("MG3D_SWEEP_REV") ? atoi(getenv("MG3D_SWEEP_REV")) : 0;
+        a.rev = ((rev_env & 1) && RES == 2) || ((rev_env & 2) && RES == 0) || ((rev_env & 4) && RES == 1) ? 1 : 0;
+    }
     long long nb = 0;
     /* XCD grouping: the blocks of one XCD group (blockIdx % 8) take a contiguous run of tile columns, so that
      * neighbouring tile columns mostly share an L2 (a tenth to a quarter fewer bytes from the fabric).  One round of

@@ -202,6 +202,15 @@ __global__ void __launch_bounds__(TINY_THREADS) tiny_up_kernel(Geom g, double *_
 #define TINY_CYC_THREADS 512
 #define TINY_PTS 7 /* ceil(15^3 / 512) */
 
+/* phase stamps of the last tiny_cycle_kernel launch (constant 100 MHz clock), written by thread 0: where the launch's
+ * time goes (tools/tiny_phases.py through mg3d_debug_tiny_stamps) */
+__device__ long long g_tiny_stamps[16];
+#define TINY_STAMP(k)                                 \
+    do {                                              \
+        if (tid == 0)                                 \
+            g_tiny_stamps[k] = (long long)wall_clock64(); \
+    } while (0)
+
 template <int RF>
 __global__ void __launch_bounds__(TINY_CYC_THREADS) tiny_cycle_kernel(Geom g, double *__restrict__ u_io,
                                                                     const double *__restrict__ d_in,
@@ -246,22 +255,40 @@ __global__ void __launch_bounds__(TINY_CYC_THREADS) tiny_cycle_kernel(Geom g, do
         __syncthreads();
     };
     /* ---- down (tiny_down_kernel): zero guess, pre-smoothing, residual, restriction */
-    /* whole-field loops: thread (j, k) walks its column along i -- one integer division per thread and kernel instead of
-     * three per point and loop (a division by a run-time value costs ~35 instructions; decoding every point in every
-     * loop was half of this kernel's time) */
-    const bool has_col = tid < N * N, has_ccol = tid < Nc * Nc;
-    const int cj = tid / N, ck = tid - cj * N, ccj = tid / Nc, cck = tid - ccj * Nc;
-    const long long gcol = (long long)g.pitch * cj + ck, gccol = (long long)gc.pitch * ccj + cck;
-    if (has_col)
-        for (int i = 0; i < N; i++) {
-            u[i * N * N + tid] = 0.;
-            d[i * N * N + tid] = d_in[g.plane * i + gcol];
+    /* whole-field loops: a thread takes the points tid, tid + 512, ...; their (i, j, k) are decoded ONCE by division and
+     * then advanced by carries -- a division by a run-time value costs ~35 instructions, and decoding every point in every
+     * loop by three of them was a third of this kernel's time */
+    TINY_STAMP(0);
+    const int di = TINY_CYC_THREADS / (N * N), dj = (TINY_CYC_THREADS / N) % N, dk = TINY_CYC_THREADS % N;
+    const int i0 = tid / (N * N), j0 = (tid / N) % N, k0 = tid % N;
+    auto advance = [&](int &i, int &j, int &k) {
+        k += dk;
+        if (k >= N) {
+            k -= N;
+            j++;
         }
+        j += dj;
+        if (j >= N) {
+            j -= N;
+            i++;
+        }
+        i += di;
+    };
+    {
+        int i = i0, j = j0, k = k0;
+        for (int t = tid; t < n; t += TINY_CYC_THREADS) {
+            u[t] = 0.;
+            d[t] = d_in[g.plane * i + (long long)g.pitch * j + k];
+            advance(i, j, k);
+        }
+    }
     __syncthreads();
+    TINY_STAMP(1);
     for (int s = 0; s < iters; s++) {
         pass(1);
         pass(0);
     }
+    TINY_STAMP(2);
 #pragma unroll
     for (int q = 0; q < TINY_PTS; q++)
         if (pt[q] >= 0) { /* mg_3d.h:819-821 */
@@ -275,34 +302,35 @@ __global__ void __launch_bounds__(TINY_CYC_THREADS) tiny_cycle_kernel(Geom g, do
             r[p] = d[p] - invHsq * s;
         }
     __syncthreads();
+    TINY_STAMP(3);
     int nonzero = 0;
     for (int t = nc + tid; t < lu.npad; t += TINY_CYC_THREADS)
         bfull[t] = 0.; /* the padding rows of the factor */
-    if (has_ccol)
-        for (int ic = 0; ic < Nc; ic++) {
-            const int jc = ccj, kc = cck, t = ic * Nc * Nc + tid;
-            const bool face = ic == 0 || ic == Nc - 1 || jc == 0 || jc == Nc - 1 || kc == 0 || kc == Nc - 1;
-            double val = 0.;
-            if (face) { /* injection, mg_3d.h:879-958, from r's boundary entries as memory holds them */
-                val = r_in[g.plane * (2 * ic) + (long long)g.pitch * (2 * jc) + 2 * kc];
-                nonzero |= (__double_as_longlong(val) << 1) != 0ll;
-                ec[t] = val; /* an identity row of the coarse operator: x = (b - (+0)) / 1 = b */
-            } else {
-                const int pf = lidx(N, 2 * ic, 2 * jc, 2 * kc);
+    for (int t = tid; t < nc; t += TINY_CYC_THREADS) { /* two rounds: the divisions are cheap here */
+        const int ic = t / (Nc * Nc), jc = (t / Nc) % Nc, kc = t % Nc;
+        const bool face = ic == 0 || ic == Nc - 1 || jc == 0 || jc == Nc - 1 || kc == 0 || kc == Nc - 1;
+        double val = 0.;
+        if (face) { /* injection, mg_3d.h:879-958, from r's boundary entries as memory holds them */
+            val = r_in[g.plane * (2 * ic) + (long long)g.pitch * (2 * jc) + 2 * kc];
+            nonzero |= (__double_as_longlong(val) << 1) != 0ll;
+            ec[t] = val; /* an identity row of the coarse operator: x = (b - (+0)) / 1 = b */
+        } else {
+            const int pf = lidx(N, 2 * ic, 2 * jc, 2 * kc);
 #pragma unroll
-                for (int ti = -1; ti <= 1; ti++)
+            for (int ti = -1; ti <= 1; ti++)
 #pragma unroll
-                    for (int tj = -1; tj <= 1; tj++)
+                for (int tj = -1; tj <= 1; tj++)
 #pragma unroll
-                        for (int tk = -1; tk <= 1; tk++) {
-                            const double w = (ti ? 0.25 : 0.5) * (tj ? 0.25 : 0.5) * (tk ? 0.25 : 0.5);
-                            val += r[pf + ti * N * N + tj * N + tk] * w;
-                        }
-            }
-            dc[gc.plane * ic + gccol] = val;
-            bfull[t] = val;
+                    for (int tk = -1; tk <= 1; tk++) {
+                        const double w = (ti ? 0.25 : 0.5) * (tj ? 0.25 : 0.5) * (tk ? 0.25 : 0.5);
+                        val += r[pf + ti * N * N + tj * N + tk] * w;
+                    }
         }
+        dc[gc.plane * ic + (long long)gc.pitch * jc + kc] = val;
+        bfull[t] = val;
+    }
     const int bad = __syncthreads_or(nonzero); /* workgroup-uniform; also: bfull, ec faces are complete */
+    TINY_STAMP(4);
     /* ---- the direct solve (gauss_elim.h:31-60) */
     if (!bad) {
         const int npi = lin.npad;
@@ -319,7 +347,9 @@ __global__ void __launch_bounds__(TINY_CYC_THREADS) tiny_cycle_kernel(Geom g, do
                 bi[q] = bfull[p];
         }
         __syncthreads(); /* bfull lies where the ring is about to be filled */
+        TINY_STAMP(5);
         lu_stream_solve<1>(lin, ring, bi, zi, dg, lane, wave);
+        TINY_STAMP(6);
         for (int p = tid; p < nc; p += TINY_CYC_THREADS) {
             const int q = lu.in_map[p];
             if (q >= 0)
@@ -347,13 +377,17 @@ __global__ void __launch_bounds__(TINY_CYC_THREADS) tiny_cycle_kernel(Geom g, do
             ec[p] = bfull[p];
     }
     __syncthreads();
-    if (has_ccol)
-        for (int ic = 0; ic < Nc; ic++)
-            xc[gc.plane * ic + gccol] = ec[ic * Nc * Nc + tid];
+    TINY_STAMP(7);
+    for (int t = tid; t < nc; t += TINY_CYC_THREADS) {
+        const int ic = t / (Nc * Nc), jc = (t / Nc) % Nc, kc = t % Nc;
+        xc[gc.plane * ic + (long long)gc.pitch * jc + kc] = ec[t];
+    }
     /* ---- up (tiny_up_kernel): prolongation + correction at every fine point (mg_3d.h:1000-1145), post-smoothing */
     const int sI = Nc * Nc, sJ = Nc, sK = 1;
-    for (int i = 0; has_col && i < N; i++) {
-        const int j = cj, k = ck, t = i * N * N + tid;
+    int pi = i0, pj = j0, pk = k0;
+    for (int t = tid; t < n; t += TINY_CYC_THREADS) {
+        const int i = pi, j = pj, k = pk;
+        advance(pi, pj, pk);
         const int oi = i & 1, oj = j & 1, ok = k & 1;
         const int c0 = (((i - oi) / 2) * Nc + (j - oj) / 2) * Nc + (k - ok) / 2;
         double x = 0.;
@@ -399,13 +433,20 @@ __global__ void __launch_bounds__(TINY_CYC_THREADS) tiny_cycle_kernel(Geom g, do
         u[t] += x;
     }
     __syncthreads();
+    TINY_STAMP(8);
     for (int s = 0; s < iters; s++) {
         pass(0);
         pass(1);
     }
-    if (has_col)
-        for (int i = 0; i < N; i++)
-            u_io[g.plane * i + gcol] = u[i * N * N + tid];
+    TINY_STAMP(9);
+    {
+        int i = i0, j = j0, k = k0;
+        for (int t = tid; t < n; t += TINY_CYC_THREADS) {
+            u_io[g.plane * i + (long long)g.pitch * j + k] = u[t];
+            advance(i, j, k);
+        }
+    }
+    TINY_STAMP(10);
 }
 
 /* Dynamic LDS above the 64 KB a kernel gets without asking (118 KB at 17^3) is granted per kernel AND per device: asked
@@ -507,4 +548,11 @@ void k_tiny_cycle(const Geom &g, double *u, const double *d, const double *r, co
     else
         hipLaunchKernelGGL(tiny_cycle_kernel<1>, dim3(1), dim3(TINY_CYC_THREADS), lds, s, g, u, d, r, gc, dc, xc, lu, lin, h * h,
                            1. / 6, 1. / (h * h), iters, sd);
+}
+
+extern "C" int mg3d_debug_tiny_stamps(long long *out16)
+{
+    if (!out16)
+        return MG3D_ERR_ARG;
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tiny_stamps), 16 * sizeof(long long)) == hipSuccess ? MG3D_OK : MG3D_ERR_HIP;
 }
