@@ -667,18 +667,28 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 }
 
 /* -------------------------------------------------------------------- launch */
-static int device_cus()
+static int current_device()
 {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev;
+}
+
+static int device_cus() /* of the CURRENT device (a process may drive several: mg3d_dist_create(device = ...)) */
+{
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cus.find(dev);
+    if (it == cus.end()) {
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-            n = p.multiProcessorCount;
+        int n = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 0;
         if (n <= 0)
             n = 256;
+        it = cus.emplace(dev, n).first;
     }
-    return n;
+    return it->second;
 }
 
 template <int S, int RES, int RJ, int NW, int PF, bool PRO = false, bool RST = true>
@@ -813,11 +823,11 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
      * into per-block partial sums, and a timing-dependent choice would make it differ from run to run */
     if (!forced && tune_on && !a.partials && T * nout >= 1024) {
         struct Key {
-            int v[12];
+            int v[13];
             bool operator<(const Key &o) const { return memcmp(v, o.v, sizeof v) < 0; }
         };
         const Key key = {{g.ni, g.nj, g.nk, g.N, g.ig0 & 1, a.i_lo, a.i_hi, a.vin != nullptr, a.partials != nullptr,
-                          a.r != nullptr, a.vk, max_partials}};
+                          a.r != nullptr, a.vk, max_partials, current_device()}};
         static std::mutex mu;
         static std::map<Key, int> tuned; /* chunk length */
         std::lock_guard<std::mutex> lock(mu);

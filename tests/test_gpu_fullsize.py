@@ -88,7 +88,7 @@ def test_admissible_coarse_grids_bit_exact_against_oracle(c, L):
         init = s.get_initial_residual()
         got = s.vcycles(2)
         u = s.download(MG3D_U, L - 1)
-    assert init == pytest.approx(want_init, rel=1e-12)
+    assert init == pytest.approx(want_init, rel=norm_rtol(N))  # tree sum on the device, sequential sum in the oracle
     assert np.array_equal(u, want_u)
     np.testing.assert_allclose(got, want_norms, rtol=norm_rtol(N), atol=0)
     if (c, L) == (3, 9):
