@@ -50,6 +50,7 @@
 
 #include <algorithm>
 #include <map>
+#include <type_traits>
 #include <mutex>
 #include <vector>
 
@@ -268,7 +269,19 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 
     /* per-row / per-column masks */
     bool row_in[RJ], row_upd[RJ], row_own[RJ], row_once[RJ];
-    long long row_off[RJ];
+    /* byte offset of the thread's pair inside a plane: 32 bits (a plane is < 4 GB), so that an access is
+     * `uniform 64-bit plane base (SGPRs) + per-lane 32-bit offset` -- the saddr form of global_load / global_store: half
+     * the address registers and no 64-bit vector add per access */
+#ifndef MG3D_DLAG
+#define MG3D_DLAG 2 /* bit 0: the four-pass smoothing shape, bit 1: every other shape -- d trails u by one plane (load_plane); same-box A/B at 513^3: residual + restriction 0.551 -> 0.532 ms, prolongation + 2 passes 0.697 -> 0.679, the four-pass shape 0.698 -> 0.706 (off there) */
+#endif
+#ifndef MG3D_ADDR32
+#define MG3D_ADDR32 3 /* same bits: 32-bit per-lane offsets instead of 64-bit ones */
+#endif
+    constexpr int SHAPE_BIT = (S == 4 && RES == 0) ? 0 : 1;
+    constexpr int DLAG = (MG3D_DLAG >> SHAPE_BIT) & 1;
+    constexpr bool A32 = ((MG3D_ADDR32 >> SHAPE_BIT) & 1) != 0;
+    typename std::conditional<A32, unsigned, long long>::type row_off[RJ];
 #pragma unroll
     for (int rr = 0; rr < RJ; rr++) {
         const int j = jrow0 + rr;
@@ -277,7 +290,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         row_own[rr] = row_in[rr] && j >= tj * VJ && j < (tj + 1) * VJ;
         /* rows no other tile column reads (the outer HJ owned rows are the neighbours' halo) */
         row_once[rr] = row_in[rr] && j >= tj * VJ + HJ && j < (tj + 1) * VJ - HJ;
-        row_off[rr] = (long long)g.pitch * j + kA;
+        row_off[rr] = (row_in[rr] && kA < g.nk) ? (decltype(row_off[0] + 0))(((long long)g.pitch * j + kA) * (long long)sizeof(double)) : 0;
     }
     const bool col_in[2] = {kA >= 0 && kA < g.nk, kA + 1 >= 0 && kA + 1 < g.nk};
     const bool col_upd[2] = {kA >= 1 && kA <= g.nk - 2, kA + 1 >= 1 && kA + 1 <= g.nk - 2};
@@ -313,28 +326,39 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     for (int c = 0; c < RJ / 2; c++)
         racc[c] = 0.;
 
+    /* u of plane i and d of plane i - 1: no stage reads d of the plane that has just arrived (stage s works on plane
+     * i - s, s >= 1), so its load trails u's by one step and lands straight in the first slot of the d window -- one
+     * slot (2 x RJ doubles: 16 VGPRs of a register file that every shape fills) less than loading both together */
     auto load_plane = [&](int i, double2(&vv)[RJ], double2(&dd)[RJ]) {
-        const bool pl = i >= 0 && i < g.ni;
-        long long pbase = g.plane * i;
-        asm volatile("" : "+s"(pbase)); /* one scalar 64-bit product per plane, not one re-materialised per row */
+        const bool pl = i >= 0 && i < g.ni, pld = i >= DLAG && i < g.ni + DLAG;
+        /* plane bases in bytes, uniform: one scalar 64-bit product per plane, not one re-materialised per row */
+        long long pbase = g.plane * i * (long long)sizeof(double), pbase_d = g.plane * (i - DLAG) * (long long)sizeof(double);
+        asm volatile("" : "+s"(pbase), "+s"(pbase_d));
+        const char *ubase = reinterpret_cast<const char *>(a.vin) + pbase, *dbase = reinterpret_cast<const char *>(a.d) + pbase_d;
 #pragma unroll
         for (int rr = 0; rr < RJ; rr++) {
+            /* vin == NULL: the input field is identically zero (a coarse level's initial guess,
+             * mg_3d.h:1258-1259) -- neither zeroed in memory beforehand nor read */
             if (pl && row_in[rr] && pair_load) {
-                const long long p = pbase + row_off[rr];
-                /* vin == NULL: the input field is identically zero (a coarse level's initial guess,
-                 * mg_3d.h:1258-1259) -- neither zeroed in memory beforehand nor read */
+                const double *p = reinterpret_cast<const double *>(ubase + row_off[rr]);
 #if (MG3D_NT & 8)
-                if (S == 0 && row_once[rr]) { /* wave-uniform */
-                    vv[rr] = a.vin ? ld_stream<8>(a.vin + p) : make_double2(0., 0.);
-                    dd[rr] = ld_stream<8>(a.d + p);
-                } else
+                if (S == 0 && row_once[rr]) /* wave-uniform */
+                    vv[rr] = a.vin ? ld_stream<8>(p) : make_double2(0., 0.);
+                else
 #endif
-                {
-                    vv[rr] = a.vin ? ld_stream<1>(a.vin + p) : make_double2(0., 0.);
-                    dd[rr] = ld_stream<4>(a.d + p);
-                }
+                    vv[rr] = a.vin ? ld_stream<1>(p) : make_double2(0., 0.);
             } else {
                 vv[rr] = make_double2(0., 0.);
+            }
+            if (pld && row_in[rr] && pair_load) {
+                const double *p = reinterpret_cast<const double *>(dbase + row_off[rr]);
+#if (MG3D_NT & 8)
+                if (S == 0 && row_once[rr])
+                    dd[rr] = ld_stream<8>(p);
+                else
+#endif
+                    dd[rr] = ld_stream<4>(p);
+            } else {
                 dd[rr] = make_double2(0., 0.);
             }
         }
@@ -465,7 +489,8 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                 e_bot[s] = (w < NW - 1) ? ex[par ^ 1][w + 1][0][s][lane] : 0.;
             }
         }
-        long long vbase = g.plane * (long long)(i - S), rbase = g.plane * (long long)(i - ST); /* store planes */
+        /* store planes, bases in bytes */
+        long long vbase = g.plane * (long long)(i - S) * (long long)sizeof(double), rbase = g.plane * (long long)(i - ST) * (long long)sizeof(double);
         asm volatile("" : "+s"(vbase), "+s"(rbase));
         /* which planes may be updated (global boundary planes / slab halos are not) */
         bool pl_upd[STX + 1], acc_ok[STX + 1];
@@ -507,7 +532,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                     km = last[rr][s - 1][0];
                     kp = lane_from_right(last[rr][s - 1][0]);
                 }
-                const double dd = dring[rr][s][X];
+                const double dd = dring[rr][s - DLAG][X]; /* DLAG: slot 0 = plane i - 1 (load_plane) */
                 const double center = (s == 1) ? in_prev[rr][X] : last[rr][s - 2][X];
                 double sum = up + dn;
                 sum = sum + jm;
@@ -545,7 +570,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                     o.x = X ? other : nw[S];
                     o.y = X ? nw[S] : other;
                     if (pair_own)
-                        st_stream(a.vout + vbase + row_off[rr], o);
+                        st_stream(reinterpret_cast<double *>(reinterpret_cast<char *>(a.vout) + vbase + row_off[rr]), o);
                 }
             }
             if constexpr (RES == 2 || (RES == 1 && RST)) { /* RST = false: the norm only, r is not assembled */
@@ -555,7 +580,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                 o.y = X ? diffs[1] : rkeep[rr];
                 rcur[rr] = o;
                 if (RES == 1 && MG3D_AND(MG3D_AND(r_ok, row_own[rr]), row_upd[rr])) { /* wave-uniform */
-                    double *dst = a.r + rbase + row_off[rr];
+                    double *dst = reinterpret_cast<double *>(reinterpret_cast<char *>(a.r) + rbase + row_off[rr]);
                     if (own_both)
                         *reinterpret_cast<double2 *>(dst) = o;
                     if (k_edge_tile) { /* boundary entries of r are never written (mg_3d.h:824-825) */
@@ -618,11 +643,11 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                 rlag[rr] = rcur[rr];
             rex[par][w][lane] = rcur[RJ - 1];
         }
-        /* age the d window */
+        /* age the d window (slots 0 .. ST-1 = planes i-1 .. i-ST) */
 #pragma unroll
         for (int rr = 0; rr < RJ; rr++)
 #pragma unroll
-            for (int s = ST; s >= 1; s--) {
+            for (int s = ST - DLAG; s >= 1; s--) {
                 dring[rr][s][0] = dring[rr][s - 1][0];
                 dring[rr][s][1] = dring[rr][s - 1][1];
             }
@@ -931,7 +956,7 @@ template <> int dispatch<4, 0>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
 }
 template <> int dispatch<2, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
-    TRY(2, 1, 4, 8, 1) TRY(2, 1, 8, 4, 2) TRY(2, 1, 6, 4, 2) TRY(2, 1, 2, 16, 1)
+    TRY(2, 1, 4, 8, 1) TRY(2, 1, 8, 4, 2) TRY(2, 1, 6, 4, 2) TRY(2, 1, 2, 16, 1) TRY(2, 1, 6, 8, 1)
     DFLT(2, 1, 4, 8, 1)
 }
 template <> int dispatch<2, 0>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
@@ -950,7 +975,7 @@ template <> int dispatch<0, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
  * partial sums written (0 when no norm was requested), -1 if the shape is unsupported. */
 template <> int dispatch<0, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
-    TRY(0, 2, 4, 8, 1) TRY(0, 2, 4, 8, 2) TRY(0, 2, 2, 8, 2) TRY(0, 2, 2, 8, 4) TRY(0, 2, 2, 16, 1)
+    TRY(0, 2, 4, 8, 1) TRY(0, 2, 4, 8, 2) TRY(0, 2, 2, 8, 2) TRY(0, 2, 2, 8, 4) TRY(0, 2, 2, 16, 1) TRY(0, 2, 6, 8, 1)
     DFLT(0, 2, 4, 8, 1)
 }
 template <> int dispatch<4, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
