@@ -483,6 +483,8 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
             return rc;
         }
         D->have_comm = true;
+        if (nranks > 1)
+            k_sweep_set_tune_default(0); /* no host-blocking first-use measurement while ranks wait for each other */
         if (nranks == 1) { /* forced: scratch for the self-addressed exchanges */
             const Geom &gt = D->rs[0].dl.back().lv.g;
             if (hipMalloc(&D->selftest, (size_t)D->H * gt.plane * sizeof(double)) != hipSuccess)

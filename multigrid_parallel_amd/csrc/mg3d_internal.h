@@ -67,6 +67,7 @@ void k_fold(const double *partials, int np, double *out, hipStream_t s);
  * vout (vout != vin; ignored when S == 0), then optionally the residual of the result: r (may be NULL)
  * receives it on the interior, partials (may be NULL) one sum of diff^2 per block.  Returns the number
  * of partials written (>= 0) or -1 when the (S, residual) shape has no instantiation. */
+void k_sweep_set_tune_default(int on); /* first-use chunk measurement on / off unless MG3D_SWEEP_TUNE says otherwise */
 int k_sweep_fuse_leg_max(); /* MG3D_FUSE_LEG_MAX: largest level side whose legs run as one launch each (default 65) */
 bool k_sweep_fuse_rst2(); /* opt-in (MG3D_FUSE_RST2=1): two passes + residual + restriction as ONE launch */
 int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,

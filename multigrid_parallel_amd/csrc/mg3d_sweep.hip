@@ -49,6 +49,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <type_traits>
 #include <mutex>
@@ -692,6 +693,13 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 }
 
 /* -------------------------------------------------------------------- launch */
+/* the first-use measurement of chunk lengths blocks the host (hipEventSynchronize) in the middle of an enqueue: fine for
+ * one process and its own stream, off by default once a process drives a real multi-rank RCCL communicator -- there every
+ * rank's stream also waits for its neighbours, and a host that stops enqueueing is one more thing that has never run on
+ * more than one GPU here (MG3D_SWEEP_TUNE=1 / 0 overrides either way) */
+static std::atomic<int> g_sweep_tune_default{1};
+void k_sweep_set_tune_default(int on) { g_sweep_tune_default.store(on); }
+
 static int current_device()
 {
     int dev = 0;
@@ -843,7 +851,7 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
      * the other buffer; every chunking gives the same bits) and the fastest is remembered for the process.
      * MG3D_SWEEP_TUNE=0 keeps the model's choice. */
     const char *tune_env = getenv("MG3D_SWEEP_TUNE");
-    const bool tune_on = !(tune_env && tune_env[0] == '0');
+    const bool tune_on = tune_env ? tune_env[0] != '0' : g_sweep_tune_default.load() != 0;
     /* not for the launches that form the norm: its value depends (in the last bits) on how the points are grouped
      * into per-block partial sums, and a timing-dependent choice would make it differ from run to run */
     if (!forced && tune_on && !a.partials && T * nout >= 1024) {

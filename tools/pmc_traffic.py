@@ -21,12 +21,8 @@ for name, ctr in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE", "T
     subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", *ctr, "--output-format", "csv", "-d", os.path.join(out, name),
                     "-o", "p", "--", *cmd], cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
-# third pass, optional: how many of the L2's memory-side read requests went on to DRAM (the rest were served by the
-# Infinity Cache, which FETCH_SIZE cannot tell apart) -- a ratio, free of the unit questions of the byte counters
-dram = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_EA0_WRREQ_sum",
-                       "TCC_EA0_WRREQ_DRAM_sum", "--output-format", "csv", "-d", os.path.join(out, "pmc_dram"), "-o", "p", "--",
-                       *cmd], cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300).returncode == 0
-
+# (TCC_EA0_RDREQ_DRAM was tried as a way to tell Infinity-Cache hits from HBM reads: it reports 100 % of the read requests
+# for every kernel -- it names the address space, not the level that served the request)
 
 def load(d):
     acc = defaultdict(lambda: defaultdict(list))
@@ -38,7 +34,6 @@ def load(d):
 
 
 A, B = load("pmc_fetch"), load("pmc_write")
-D = load("pmc_dram") if dram else {}
 timer_of = {"sweep_kernel<4, 0,": "sweep4", "sweep_kernel<0, 2,": "residual", "sweep_kernel<2, 1,": "sweep2+residual",
             "sweep_kernel<2, 0,": "sweep2", "prolong_cell_kernel": "prolong"}
 res, lines = {}, []
@@ -60,12 +55,6 @@ for k in sorted(A, key=lambda k: -max(sum(v) / len(v) for (g, c), v in A[k].item
     rd, wr = 2 * fetch_kb * 1024, mean((g, "WRITE_SIZE")) * 1024
     lines.append(f"{k[:66]:66s} | grid {g:9d} | n={n:3d} | read {rd / 1e9:6.3f} GB (2 x FETCH_SIZE) | written {wr / 1e9:6.3f} GB | "
                  f"L2 hit {mean((g, 'TCC_HIT_sum')):.4g} miss {mean((g, 'TCC_MISS_sum')):.4g} | HBM-side bytes/launch {(rd + wr) / 1e9:6.3f} GB")
-    if k in D:
-        dsel = D[k]
-        dm = lambda c: steady(dsel, c, g)[1]
-        rq, rqd, wq, wqd = dm("TCC_EA0_RDREQ_sum"), dm("TCC_EA0_RDREQ_DRAM_sum"), dm("TCC_EA0_WRREQ_sum"), dm("TCC_EA0_WRREQ_DRAM_sum")
-        if rq > 0:
-            lines[-1] += f" | EA read requests to DRAM {100 * rqd / rq:5.1f} %, writes {100 * wqd / max(wq, 1):5.1f} %"
     for pat, t in timer_of.items():
         if pat in k and t not in res:
             res[t] = rd + wr
