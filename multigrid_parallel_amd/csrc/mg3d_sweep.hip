@@ -291,12 +291,16 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         row_own[rr] = row_in[rr] && j >= tj * VJ && j < (tj + 1) * VJ;
         /* rows no other tile column reads (the outer HJ owned rows are the neighbours' halo) */
         row_once[rr] = row_in[rr] && j >= tj * VJ + HJ && j < (tj + 1) * VJ - HJ;
-        row_off[rr] = (row_in[rr] && kA < g.nk) ? (decltype(row_off[0] + 0))(((long long)g.pitch * j + kA) * (long long)sizeof(double)) : 0;
+        /* loads are UNCONDITIONAL (load_plane): rows, columns and planes outside the level are clamped onto it.  What
+         * they deliver there is never used -- a point of the level only reads neighbours inside the level, and the points
+         * on its faces are passed through, not computed -- so clamping replaces a guard (two scalar ANDs, an EXEC save, a
+         * branch and a restore per row and field: half of the step's scalar instructions) by nothing */
+        const int jc = j < 0 ? 0 : (j >= g.nj ? g.nj - 1 : j), kc = kA > g.pitch - 2 ? g.pitch - 2 : kA;
+        row_off[rr] = (decltype(row_off[0] + 0))(((long long)g.pitch * jc + kc) * (long long)sizeof(double));
     }
     const bool col_in[2] = {kA >= 0 && kA < g.nk, kA + 1 >= 0 && kA + 1 < g.nk};
     const bool col_upd[2] = {kA >= 1 && kA <= g.nk - 2, kA + 1 >= 1 && kA + 1 <= g.nk - 2};
     const bool pair_own = kA >= own_klo && kA < own_khi && col_in[0];
-    const bool pair_load = col_in[0]; /* kA even and pitch even: the 16-byte load stays inside the row */
     /* lane masks used inside the plane loop (the row flags are wave-uniform scalars) */
     const bool own_upd[2] = {pair_own && col_upd[0], pair_own && col_upd[1]};
     const bool own_both = own_upd[0] && own_upd[1], own_only0 = own_upd[0] && !col_upd[1],
@@ -331,36 +335,27 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
      * i - s, s >= 1), so its load trails u's by one step and lands straight in the first slot of the d window -- one
      * slot (2 x RJ doubles: 16 VGPRs of a register file that every shape fills) less than loading both together */
     auto load_plane = [&](int i, double2(&vv)[RJ], double2(&dd)[RJ]) {
-        const bool pl = i >= 0 && i < g.ni, pld = i >= DLAG && i < g.ni + DLAG;
+        const int iu = i < 0 ? 0 : (i >= g.ni ? g.ni - 1 : i), id = i - DLAG < 0 ? 0 : (i - DLAG >= g.ni ? g.ni - 1 : i - DLAG);
         /* plane bases in bytes, uniform: one scalar 64-bit product per plane, not one re-materialised per row */
-        long long pbase = g.plane * i * (long long)sizeof(double), pbase_d = g.plane * (i - DLAG) * (long long)sizeof(double);
+        long long pbase = g.plane * iu * (long long)sizeof(double), pbase_d = g.plane * id * (long long)sizeof(double);
         asm volatile("" : "+s"(pbase), "+s"(pbase_d));
         const char *ubase = reinterpret_cast<const char *>(a.vin) + pbase, *dbase = reinterpret_cast<const char *>(a.d) + pbase_d;
+        /* vin == NULL: the input field is identically zero (a coarse level's initial guess, mg_3d.h:1258-1259) --
+         * neither zeroed in memory beforehand nor read */
+        const bool have_u = a.vin != nullptr; /* uniform */
 #pragma unroll
         for (int rr = 0; rr < RJ; rr++) {
-            /* vin == NULL: the input field is identically zero (a coarse level's initial guess,
-             * mg_3d.h:1258-1259) -- neither zeroed in memory beforehand nor read */
-            if (pl && row_in[rr] && pair_load) {
-                const double *p = reinterpret_cast<const double *>(ubase + row_off[rr]);
+            const double *pu = reinterpret_cast<const double *>(ubase + row_off[rr]);
+            const double *pd = reinterpret_cast<const double *>(dbase + row_off[rr]);
 #if (MG3D_NT & 8)
-                if (S == 0 && row_once[rr]) /* wave-uniform */
-                    vv[rr] = a.vin ? ld_stream<8>(p) : make_double2(0., 0.);
-                else
+            if (S == 0 && row_once[rr]) { /* wave-uniform */
+                vv[rr] = have_u ? ld_stream<8>(pu) : make_double2(0., 0.);
+                dd[rr] = ld_stream<8>(pd);
+            } else
 #endif
-                    vv[rr] = a.vin ? ld_stream<1>(p) : make_double2(0., 0.);
-            } else {
-                vv[rr] = make_double2(0., 0.);
-            }
-            if (pld && row_in[rr] && pair_load) {
-                const double *p = reinterpret_cast<const double *>(dbase + row_off[rr]);
-#if (MG3D_NT & 8)
-                if (S == 0 && row_once[rr])
-                    dd[rr] = ld_stream<8>(p);
-                else
-#endif
-                    dd[rr] = ld_stream<4>(p);
-            } else {
-                dd[rr] = make_double2(0., 0.);
+            {
+                vv[rr] = have_u ? ld_stream<1>(pu) : make_double2(0., 0.);
+                dd[rr] = ld_stream<4>(pd);
             }
         }
     };
