@@ -268,11 +268,30 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     /* the fused restriction finishes a coarse plane one fine plane after its centre, one step late */
     const int nsteps = (i_out1 - 1 + ST) - i_s + 1 + (RES == 2 ? 2 : 0);
 
+    /* plane ranges of this segment as (first plane, last - first); an empty range never matches */
+    const int upd_first = max(1, 1 - g.ig0), upd_last = min(g.ni - 2, g.N - 2 - g.ig0);
+    const int upd_lo = upd_last >= upd_first ? upd_first : 0x3fffffff;
+    const unsigned upd_span = upd_last >= upd_first ? (unsigned)(upd_last - upd_first) : 0u;
+    const int nrm_first = max(i_out0, a.acc_lo), nrm_last = min(i_out1, a.acc_hi) - 1;
+    const bool nrm_any = a.partials != nullptr && nrm_last >= nrm_first;
+    const int nrm_lo = nrm_any ? nrm_first : 0x3fffffff;
+    const unsigned nrm_span = nrm_any ? (unsigned)(nrm_last - nrm_first) : 0u;
+
+    /* RES == 2: fine planes qq (odd global index) behind which a coarse plane is complete AND to be stored:
+     * centre qq - 1 in [i_out0, i_out1), coarse plane (ig0 + qq - 1) / 2 in [1, Nc - 2] and in [ic_lo, ic_hi) locally */
+    const int rst_first = max(max(i_out0 + 1, 3 - g.ig0), 2 * (a.ic_lo + a.gc.ig0) + 1 - g.ig0);
+    const int rst_last = min(min(i_out1, 2 * a.gc.N - 3 - g.ig0), 2 * (a.ic_hi - 1 + a.gc.ig0) + 1 - g.ig0);
+    const int rst_lo = rst_last >= rst_first ? rst_first : 0x3fffffff;
+    const unsigned rst_span = rst_last >= rst_first ? (unsigned)(rst_last - rst_first) : 0u;
+
     /* per-row / per-column masks */
     bool row_in[RJ], row_upd[RJ], row_own[RJ], row_once[RJ];
     /* byte offset of the thread's pair inside a plane: 32 bits (a plane is < 4 GB), so that an access is
      * `uniform 64-bit plane base (SGPRs) + per-lane 32-bit offset` -- the saddr form of global_load / global_store: half
      * the address registers and no 64-bit vector add per access */
+#ifndef MG3D_EDGE_UNCOND
+#define MG3D_EDGE_UNCOND 0 /* 1: the wave-edge LDS rows are read without a test in every shape */
+#endif
 #ifndef MG3D_DLAG
 #define MG3D_DLAG 2 /* bit 0: the four-pass smoothing shape, bit 1: every other shape -- d trails u by one plane (load_plane); same-box A/B at 513^3: residual + restriction 0.551 -> 0.532 ms, prolongation + 2 passes 0.697 -> 0.679, the four-pass shape 0.698 -> 0.706 (off there) */
 #endif
@@ -306,6 +325,16 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     const bool own_both = own_upd[0] && own_upd[1], own_only0 = own_upd[0] && !col_upd[1],
                own_only1 = own_upd[1] && !col_upd[0];
     const bool k_edge_tile = tk == 0 || tk == a.ntk - 1; /* only there a pair can have one updatable column */
+    /* RES == 2: the coarse points this thread completes -- rows centred on its even rows, its even column */
+    bool crow_ok[RJ / 2];
+    long long dc_off[RJ / 2];
+    const bool ccol_ok = pair_own && (kA >> 1) >= 1 && (kA >> 1) <= a.gc.nk - 2;
+#pragma unroll
+    for (int c = 0; c < RJ / 2; c++) {
+        const int jc = (jrow0 + 2 * c) >> 1;
+        crow_ok[c] = row_own[2 * c] && jc >= 1 && jc <= a.gc.nj - 2;
+        dc_off[c] = (long long)a.gc.pitch * jc + (kA >> 1);
+    }
 
     /* pipeline state (see header).  last[rr][s][c]: newest stage-s output of column c */
     double last[RJ][STX][2], in_prev[RJ][2], dring[RJ][ST + 1][2], rkeep[RJ];
@@ -477,7 +506,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
              * the grid), whose results are never used -- it reads its own row instead of branching around the read.
              * Not in the two shapes that sit at 256 VGPRs: there the eight unconditional reads at the top of the step
              * lengthen live ranges into scratch spills inside the plane loop (measured 0.68 -> 0.94 ms at 513^3). */
-            if constexpr (S < 4 && (RES != 2 || PF == 1)) {
+            if constexpr (MG3D_EDGE_UNCOND || (S < 4 && (RES != 2 || PF == 1))) {
                 e_top[s] = ex[par ^ 1][w > 0 ? w - 1 : 0][1][s][lane];
                 e_bot[s] = ex[par ^ 1][w < NW - 1 ? w + 1 : NW - 1][0][s][lane];
             } else {
@@ -488,22 +517,19 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         /* store planes, bases in bytes */
         long long vbase = g.plane * (long long)(i - S) * (long long)sizeof(double), rbase = g.plane * (long long)(i - ST) * (long long)sizeof(double);
         asm volatile("" : "+s"(vbase), "+s"(rbase));
-        /* which planes may be updated (global boundary planes / slab halos are not) */
+        /* which planes may be updated (global boundary planes / slab halos are not), which enter the norm, which are
+         * stored: each a range of planes fixed per segment (upd_lo .. below), tested with ONE unsigned compare
+         * (q - lo <= span) instead of four signed ones and the branches a short-circuit turns them into */
         bool pl_upd[STX + 1], acc_ok[STX + 1];
 #pragma unroll
         for (int s = 1; s <= ST; s++) {
             const int q = i - s;
-            pl_upd[s] = q >= 1 && q <= g.ni - 2 && (g.ig0 + q) >= 1 && (g.ig0 + q) <= g.N - 2;
-            /* planes that enter the norm (none without a norm) */
-            if constexpr (RES == 1)
-                acc_ok[s] = (a.partials != nullptr) & (q >= i_out0) & (q < i_out1) & (q >= a.acc_lo) & (q < a.acc_hi);
-            else
-                acc_ok[s] = a.partials && q >= i_out0 && q < i_out1 && q >= a.acc_lo && q < a.acc_hi;
+            pl_upd[s] = (unsigned)(q - upd_lo) <= upd_span;
+            acc_ok[s] = RES == 1 ? (unsigned)(q - nrm_lo) <= nrm_span : false; /* planes that enter the norm */
         }
         /* this step's store planes lie in the output range (wave-uniform, once per step, not once per row) */
-        const bool v_ok = RES == 1 ? (i - S >= i_out0) & (i - S < i_out1) : (i - S >= i_out0 && i - S < i_out1);
-        const bool r_ok = RES == 1 ? (a.r != nullptr) & (i - ST >= i_out0) & (i - ST < i_out1) & pl_upd[ST]
-                                   : (a.r && i - ST >= i_out0 && i - ST < i_out1 && pl_upd[ST]);
+        const bool v_ok = (unsigned)(i - S - i_out0) < (unsigned)len;
+        const bool r_ok = RES == 1 ? (a.r != nullptr) & ((unsigned)(i - ST - i_out0) < (unsigned)len) & pl_upd[ST] : false;
 /* wave-uniform tests joined without short-circuit where that is free (one scalar AND instead of a branch per operand);
  * the restriction shape spills with it (scratch 36 -> 96 bytes, 0.59 -> 1.0 ms), the pure smoothers gain nothing */
 #define MG3D_AND(x, y) (RES == 1 ? ((x) & (y)) : ((x) && (y)))
@@ -617,13 +643,13 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                 for (int t = 0; t < 9; t++)
                     run = run + p[t];
                 if (odd) {
-                    /* qq is the ti = 2 plane of coarse plane (qg-1)/2 and the ti = 0 plane of (qg+1)/2 */
-                    const int icg = (qg - 1) >> 1, icl = icg - a.gc.ig0, cen = qq - 1;
-                    const int jc = (jrow0 + 2 * c) >> 1, kc = kA >> 1;
-                    if (cen >= i_out0 && cen < i_out1 && icg >= 1 && icg <= a.gc.N - 2 && icl >= a.ic_lo && icl < a.ic_hi &&
-                        row_own[2 * c] && jc >= 1 && jc <= a.gc.nj - 2) { /* wave-uniform */
-                        if (pair_own && kc >= 1 && kc <= a.gc.nk - 2)
-                            a.dc[a.gc.plane * icl + (long long)a.gc.pitch * jc + kc] = run;
+                    /* qq is the ti = 2 plane of coarse plane (qg-1)/2 and the ti = 0 plane of (qg+1)/2.  The coarse plane
+                     * is stored when its centre plane qq - 1 lies in this segment's output range, it is an interior
+                     * plane of the coarse level and one this launch is to write: one range of qq (rst_lo, rst_span) */
+                    if (((unsigned)(qq - rst_lo) <= rst_span) & crow_ok[c]) { /* wave-uniform */
+                        const int icl = ((qg - 1) >> 1) - a.gc.ig0;
+                        if (ccol_ok)
+                            a.dc[a.gc.plane * icl + dc_off[c]] = run;
                     }
                     double fresh = 0.;
 #pragma unroll
