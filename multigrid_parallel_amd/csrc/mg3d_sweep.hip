@@ -268,6 +268,10 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     /* the fused restriction finishes a coarse plane one fine plane after its centre, one step late */
     const int nsteps = (i_out1 - 1 + ST) - i_s + 1 + (RES == 2 ? 2 : 0);
 
+    /* a plane in bytes fits 32 bits (the largest level the context admits, 2049^3: 34 MB a plane), so a plane's base is
+     * ONE 32 x 32 -> 64-bit scalar product, not the 64 x 64-bit one `long long * int` compiles to (eight scalar
+     * instructions a product, four products a step) */
+    const unsigned plane_bytes = (unsigned)(g.plane * (long long)sizeof(double));
     /* plane ranges of this segment as (first plane, last - first); an empty range never matches */
     const int upd_first = max(1, 1 - g.ig0), upd_last = min(g.ni - 2, g.N - 2 - g.ig0);
     const int upd_lo = upd_last >= upd_first ? upd_first : 0x3fffffff;
@@ -366,7 +370,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     auto load_plane = [&](int i, double2(&vv)[RJ], double2(&dd)[RJ]) {
         const int iu = i < 0 ? 0 : (i >= g.ni ? g.ni - 1 : i), id = i - DLAG < 0 ? 0 : (i - DLAG >= g.ni ? g.ni - 1 : i - DLAG);
         /* plane bases in bytes, uniform: one scalar 64-bit product per plane, not one re-materialised per row */
-        long long pbase = g.plane * iu * (long long)sizeof(double), pbase_d = g.plane * id * (long long)sizeof(double);
+        long long pbase = (long long)((unsigned long long)plane_bytes * (unsigned)iu), pbase_d = (long long)((unsigned long long)plane_bytes * (unsigned)id);
         asm volatile("" : "+s"(pbase), "+s"(pbase_d));
         const char *ubase = reinterpret_cast<const char *>(a.vin) + pbase, *dbase = reinterpret_cast<const char *>(a.d) + pbase_d;
         /* vin == NULL: the input field is identically zero (a coarse level's initial guess, mg_3d.h:1258-1259) --
@@ -515,7 +519,8 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
             }
         }
         /* store planes, bases in bytes */
-        long long vbase = g.plane * (long long)(i - S) * (long long)sizeof(double), rbase = g.plane * (long long)(i - ST) * (long long)sizeof(double);
+        /* (planes outside the level: any product will do, the stores are guarded by v_ok / r_ok) */
+        long long vbase = (long long)((unsigned long long)plane_bytes * (unsigned)(i - S)), rbase = (long long)((unsigned long long)plane_bytes * (unsigned)(i - ST));
         asm volatile("" : "+s"(vbase), "+s"(rbase));
         /* which planes may be updated (global boundary planes / slab halos are not), which enter the norm, which are
          * stored: each a range of planes fixed per segment (upd_lo .. below), tested with ONE unsigned compare
