@@ -294,10 +294,12 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
      * `uniform 64-bit plane base (SGPRs) + per-lane 32-bit offset` -- the saddr form of global_load / global_store: half
      * the address registers and no 64-bit vector add per access */
 #ifndef MG3D_EDGE_UNCOND
-#define MG3D_EDGE_UNCOND 0 /* 1: the wave-edge LDS rows are read without a test in every shape */
+#define MG3D_EDGE_UNCOND 1 /* 1: the wave-edge LDS rows are read without a test in every shape (with MG3D_DLAG = 3 the
+                              * four-pass shape has the registers for it: 252 VGPRs, no scratch; 257^3 0.120 -> 0.108 ms,
+                              * 129^3 0.033 -> 0.028; with MG3D_DLAG = 2 it spills and loses 20 %) */
 #endif
 #ifndef MG3D_DLAG
-#define MG3D_DLAG 2 /* bit 0: the four-pass smoothing shape, bit 1: every other shape -- d trails u by one plane (load_plane); same-box A/B at 513^3: residual + restriction 0.551 -> 0.532 ms, prolongation + 2 passes 0.697 -> 0.679, the four-pass shape 0.698 -> 0.706 (off there) */
+#define MG3D_DLAG 3 /* bit 0: the four-pass smoothing shape, bit 1: every other shape -- d trails u by one plane (load_plane); same-box A/B at 513^3: residual + restriction 0.551 -> 0.532 ms, prolongation + 2 passes 0.697 -> 0.679; the four-pass shape needs it to run without scratch once its edge rows are read unconditionally */
 #endif
 #ifndef MG3D_ADDR32
 #define MG3D_ADDR32 3 /* same bits: 32-bit per-lane offsets instead of 64-bit ones */
@@ -376,20 +378,32 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         /* vin == NULL: the input field is identically zero (a coarse level's initial guess, mg_3d.h:1258-1259) --
          * neither zeroed in memory beforehand nor read */
         const bool have_u = a.vin != nullptr; /* uniform */
+        /* (one uniform test for the whole plane, not one per row: the rows' loads stay a straight line) */
+        if (have_u) {
+#pragma unroll
+            for (int rr = 0; rr < RJ; rr++) {
+                const double *pu = reinterpret_cast<const double *>(ubase + row_off[rr]);
+#if (MG3D_NT & 8)
+                if (S == 0 && row_once[rr]) /* wave-uniform */
+                    vv[rr] = ld_stream<8>(pu);
+                else
+#endif
+                    vv[rr] = ld_stream<1>(pu);
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < RJ; rr++)
+                vv[rr] = make_double2(0., 0.);
+        }
 #pragma unroll
         for (int rr = 0; rr < RJ; rr++) {
-            const double *pu = reinterpret_cast<const double *>(ubase + row_off[rr]);
             const double *pd = reinterpret_cast<const double *>(dbase + row_off[rr]);
 #if (MG3D_NT & 8)
-            if (S == 0 && row_once[rr]) { /* wave-uniform */
-                vv[rr] = have_u ? ld_stream<8>(pu) : make_double2(0., 0.);
+            if (S == 0 && row_once[rr])
                 dd[rr] = ld_stream<8>(pd);
-            } else
+            else
 #endif
-            {
-                vv[rr] = have_u ? ld_stream<1>(pu) : make_double2(0., 0.);
                 dd[rr] = ld_stream<4>(pd);
-            }
         }
     };
 
@@ -402,14 +416,19 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     auto slot_of = [](int c) { return ((c % 3) + 3) % 3; };
     constexpr int CPT = PRO ? (CRW * CCW + NW * WAVE - 1) / (NW * WAVE) : 1; /* staged values per thread */
     auto coarse_fetch = [&](int c, double(&buf)[CPT]) {
+        /* unconditional, from clamped indices (as load_plane): a fine point of the level has its parents inside the
+         * coarse level, what is staged for positions outside it is never used */
+        const int cc = c < 0 ? 0 : (c >= a.gce.ni ? a.gce.ni - 1 : c);
+        const long long cbase = a.gce.plane * cc;
 #pragma unroll
         for (int t = 0; t < CPT; t++) {
-            const int idx = threadIdx.x + t * NW * WAVE;
+            int idx = threadIdx.x + t * NW * WAVE;
+            idx = idx < CRW * CCW ? idx : CRW * CCW - 1;
             const int row = idx / CCW, col = idx - row * CCW;
-            const int jc = jcb + row, kc = kcb + col;
-            const bool ok = idx < CRW * CCW && c >= 0 && c < a.gce.ni && jc >= 0 && jc < a.gce.nj && kc >= 0 &&
-                            kc < a.gce.nk;
-            buf[t] = ok ? a.ec[a.gce.plane * c + (long long)a.gce.pitch * jc + kc] : 0.;
+            int jc = jcb + row, kc = kcb + col;
+            jc = jc < 0 ? 0 : (jc >= a.gce.nj ? a.gce.nj - 1 : jc);
+            kc = kc < 0 ? 0 : (kc >= a.gce.nk ? a.gce.nk - 1 : kc);
+            buf[t] = a.ec[cbase + (long long)a.gce.pitch * jc + kc];
         }
     };
     auto coarse_put = [&](int c, const double(&buf)[CPT]) {
