@@ -1053,8 +1053,11 @@ int k_sweep_small_max() /* levels of at most this many points per side use the t
 
 int k_sweep_fuse_leg_max() /* levels of at most this many points per side run a whole leg of the cycle as ONE launch */
 {
-    const char *e = getenv("MG3D_FUSE_LEG_MAX"); /* 0: never */
-    return e ? atoi(e) : 65;
+    /* default 0 (never) since round 3: with the guards gone from the plane loop the four-row launches of a 65^3 level
+     * (four passes 12 us + residual / restriction 9 us) undercut the six-stage two-row leg (29 us), which keeps a quarter
+     * of the rows it computes; 513^3: 3.052 against 3.053 ms per cycle, 129^3: 0.233 against 0.239 ms */
+    const char *e = getenv("MG3D_FUSE_LEG_MAX");
+    return e ? atoi(e) : 0;
 }
 
 bool k_sweep_fuse_rst2() /* MG3D_FUSE_RST2=1: keep the one-launch shape for two passes + residual + restriction */

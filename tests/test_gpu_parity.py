@@ -717,10 +717,10 @@ def test_measured_chunk_length_changes_no_bit(monkeypatch):
 @pytest.mark.parametrize("c,L,nu", [(9, 4, 2), (5, 5, 2), (3, 6, 2), (7, 4, 2), (9, 5, 2), (6, 4, 3)])
 @pytest.mark.parametrize("small,legs", [("0", "0"), ("65", "0"), ("0", "65"), ("1000", "1000")])
 def test_small_level_policy_changes_no_bit(monkeypatch, c, L, nu, small, legs):
-    """Levels of at most 65^3 points run the two-rows-per-thread shapes with two planes in flight (MG3D_SMALL_MAX) and,
-    for V(2,2), each leg of the cycle as ONE launch (four passes + residual + restriction; prolongation + four passes:
-    MG3D_FUSE_LEG_MAX).  Either policy off, both off, or both forced onto every level: the same bits as the default, and
-    the default equals the oracle."""
+    """Levels of at most 65^3 points run the two-rows-per-thread shapes with two planes in flight (MG3D_SMALL_MAX); for
+    V(2,2) each leg of the cycle can run as ONE launch (four passes + residual + restriction; prolongation + four passes:
+    MG3D_FUSE_LEG_MAX, the default up to round 2, opt-in since).  Either policy off, both off, or both forced onto every
+    level: the same bits as the default, and the default equals the oracle."""
     res = []
     for env in ({}, {"MG3D_SMALL_MAX": small, "MG3D_FUSE_LEG_MAX": legs}):
         for k in ("MG3D_SMALL_MAX", "MG3D_FUSE_LEG_MAX"):
