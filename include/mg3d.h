@@ -132,6 +132,9 @@ enum {
     MG3D_K_SWEEP2_RES,   /* fused sweep, 2 colour passes + residual */
     MG3D_K_RESIDUAL,     /* residual (+ r store) of the current field */
     MG3D_K_RESTRICT, MG3D_K_PROLONG, MG3D_K_COARSE_SOLVE, MG3D_K_COLOUR_PASS,
+    MG3D_K_SWEEP4_NORM,     /* carried cycles (mg3d_vcycles): a cycle's last 2 post-smoothing passes, its residual norm and
+                               the next cycle's first pre-smoothing passes in one launch */
+    MG3D_K_SWEEP1_RESTRICT, /* carried cycles: the last pre-smoothing pass + residual + restriction */
     MG3D_NUM_KERNELS
 };
 const char *mg3d_kernel_name(int kernel);

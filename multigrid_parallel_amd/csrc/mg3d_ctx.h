@@ -42,6 +42,10 @@ struct mg3d_ctx {
     /* the mixed-boundary problem of csrc/mg3d_es.hip, after mg3d_es_setup */
     bool have_es;
     mg3d_es_params es;
+    /* carried cycles (mg3d_vcycles, see mg3d_enqueue_vcycle): u of the top level already holds the first three
+     * pre-smoothing passes of the NEXT cycle; the finished cycle's own result is in the level's alt buffer */
+    bool carried;
+    bool raw_top; /* a raw device pointer to u or d of the top level was handed out (mg3d_device_view) */
     bool fused; /* fused sweep kernel (default) or one launch per colour pass (MG3D_NO_FUSE=1) */
     int timing; /* 0 off, 1 every level, 2 finest level only, 3 finest level's kernel timers only, 4 + k: 3 on every (k+2)-th cycle */
     int timing_phase; /* cycles since the last sampled one (timing >= 4) */
@@ -61,6 +65,10 @@ void mg3d_ctx_touched(mg3d_ctx *ctx, int field, int level, bool raw_pointer = fa
 /* records a failure text for mg3d_last_error() and returns `code` */
 int mg3d_fail(int code, const char *fmt, ...);
 /* enqueue one V-cycle from level q of a (single-domain) context; squared norm of level q to sumsq[slot] */
-int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot);
+/* carry_out: end the cycle with the launch that also starts the next one (only mg3d_vcycles asks, and never for the
+ * last cycle of a call); ignored where mg3d_can_carry() says no */
+int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, bool carry_out = false);
+bool mg3d_can_carry(const mg3d_ctx *ctx, int q);
+void mg3d_drop_carry(mg3d_ctx *ctx); /* carried state -> the finished cycle's own u; a no-op otherwise */
 
 #endif

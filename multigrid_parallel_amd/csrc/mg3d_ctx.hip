@@ -52,7 +52,8 @@ static const char *const kStageNames[MG3D_NUM_STAGES] = {"Smoother1",          "
                                                          "CalcResidual2"}; /* mg_3d.h:136-137 */
 
 static const char *const kKernelNames[MG3D_NUM_KERNELS] = {"sweep4", "sweep2", "sweep2+residual", "residual",
-                                                           "restrict", "prolong", "coarse_solve", "colour_pass"};
+                                                           "restrict", "prolong", "coarse_solve", "colour_pass",
+                                                           "sweep4+norm", "sweep1+restrict"};
 
 extern "C" const char *mg3d_kernel_name(int k) { return (k >= 0 && k < MG3D_NUM_KERNELS) ? kKernelNames[k] : "?"; }
 
@@ -211,6 +212,8 @@ static mg3d_ctx *ctx_new(int L, int iters)
     ctx->faces_dirty.assign(L, 1);
     ctx->faces_always.assign(L, 0);
     ctx->fused = true;
+    ctx->carried = false;
+    ctx->raw_top = false;
     ctx->keep_r = false;
     if (const char *e = getenv("MG3D_KEEP_R"))
         ctx->keep_r = e[0] == '1';
@@ -219,8 +222,31 @@ static mg3d_ctx *ctx_new(int L, int iters)
     return ctx;
 }
 
+/* carried cycles (see mg3d_enqueue_vcycle): back to the finished cycle's own result.  The launch that carried the cycle
+ * over took u behind the cycle's first two post-smoothing passes (still intact in the alt buffer) through its last two,
+ * tapped the norm there and went on into the next cycle: the finished cycle's u itself was never written.  It is those
+ * two passes (black, red) from alt -- one launch, paid only when somebody wants to see or change the state between two
+ * cycles.  Every entry point that reads or writes level data, or changes what a cycle is, calls this first; only
+ * mg3d_vcycle(s) continue from the carried state. */
+void mg3d_drop_carry(mg3d_ctx *ctx)
+{
+    if (!ctx || !ctx->carried)
+        return;
+    Level &l = ctx->lv[ctx->L - 1];
+    ctx->carried = false;
+    const int np = k_sweep(l.g, l.alt, l.f[MG3D_D], l.f[MG3D_U], nullptr, nullptr, MG3D_MAX_PARTIALS, l.h, 2, 0, false,
+                           ctx->stream);
+    if (np < 0)
+        (void)fail(MG3D_ERR_STATE, "carried cycle: the two passes that finish it could not be launched");
+}
+#define drop_carry mg3d_drop_carry
+
 void mg3d_ctx_touched(mg3d_ctx *ctx, int field, int level, bool raw_pointer)
 {
+    /* a raw device pointer to u or d of the top level: the library no longer sees every write to them, so a single
+     * mg3d_vcycle call does not run ahead into the next cycle any more (mg3d_vcycles still carries INSIDE a call) */
+    if (raw_pointer && level == ctx->L - 1 && (field == MG3D_U || field == MG3D_D))
+        ctx->raw_top = true;
     const int l = field == MG3D_R ? level : field == MG3D_D ? level + 1 : -1;
     if (l >= 1 && l < ctx->L) {
         ctx->faces_dirty[l] = 1;
@@ -307,6 +333,7 @@ extern "C" double mg3d_ctx_level_h(const mg3d_ctx *ctx, int level)
 }
 extern "C" int mg3d_ctx_set_keep_residual(mg3d_ctx *ctx, int keep)
 {
+    mg3d_drop_carry(ctx);
     if (!ctx)
         return fail(MG3D_ERR_ARG, "mg3d_ctx_set_keep_residual: NULL context");
     ctx->keep_r = keep != 0;
@@ -315,6 +342,7 @@ extern "C" int mg3d_ctx_set_keep_residual(mg3d_ctx *ctx, int keep)
 
 extern "C" int mg3d_ctx_set_smooth_iters(mg3d_ctx *ctx, int iters)
 {
+    mg3d_drop_carry(ctx);
     if (!ctx || iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_ctx_set_smooth_iters: bad arguments");
     ctx->iters = iters;
@@ -460,6 +488,7 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
 
 extern "C" int mg3d_ctx_set_lu(mg3d_ctx *ctx, const double *LU)
 {
+    mg3d_drop_carry(ctx);
     if (!ctx || !LU)
         return fail(MG3D_ERR_ARG, "mg3d_ctx_set_lu: NULL argument");
     const int N0 = ctx->lv[0].g.N;
@@ -475,6 +504,7 @@ extern "C" int mg3d_ctx_set_lu(mg3d_ctx *ctx, const double *LU)
 
 extern "C" int mg3d_ctx_build_coarse(mg3d_ctx *ctx, double h_coarse)
 {
+    mg3d_drop_carry(ctx);
     if (!ctx)
         return fail(MG3D_ERR_ARG, "mg3d_ctx_build_coarse: NULL context");
     const int N0 = ctx->lv[0].g.N;
@@ -501,6 +531,7 @@ static int check_field_level(const mg3d_ctx *ctx, int field, int level, const ch
 
 extern "C" int mg3d_upload(mg3d_ctx *ctx, int field, int level, const double *host)
 {
+    mg3d_drop_carry(ctx);
     CHK(check_field_level(ctx, field, level, "mg3d_upload"));
     if (!host)
         return fail(MG3D_ERR_ARG, "mg3d_upload: NULL host pointer");
@@ -515,6 +546,7 @@ extern "C" int mg3d_upload(mg3d_ctx *ctx, int field, int level, const double *ho
 
 extern "C" int mg3d_download(mg3d_ctx *ctx, int field, int level, double *host)
 {
+    mg3d_drop_carry(ctx);
     CHK(check_field_level(ctx, field, level, "mg3d_download"));
     if (!host)
         return fail(MG3D_ERR_ARG, "mg3d_download: NULL host pointer");
@@ -528,6 +560,7 @@ extern "C" int mg3d_download(mg3d_ctx *ctx, int field, int level, double *host)
 
 extern "C" int mg3d_zero(mg3d_ctx *ctx, int field, int level)
 {
+    mg3d_drop_carry(ctx);
     CHK(check_field_level(ctx, field, level, "mg3d_zero"));
     const Level &l = ctx->lv[level];
     HIPCHK(hipMemsetAsync(l.f[field], 0, l.elems * sizeof(double), ctx->stream));
@@ -547,6 +580,7 @@ extern "C" int mg3d_sync(mg3d_ctx *ctx)
 extern "C" int mg3d_device_view(mg3d_ctx *ctx, int field, int level, void **dev_ptr, int *pitch_doubles,
                                 long *plane_doubles)
 {
+    mg3d_drop_carry(ctx);
     CHK(check_field_level(ctx, field, level, "mg3d_device_view"));
     const Level &l = ctx->lv[level];
     mg3d_ctx_touched(ctx, field, level, true);
@@ -706,6 +740,7 @@ static int enqueue_residual(mg3d_ctx *ctx, int level, int store, int slot)
 
 extern "C" int mg3d_smooth(mg3d_ctx *ctx, int level, int post, int iters)
 {
+    mg3d_drop_carry(ctx);
     CHK(check_field_level(ctx, 0, level, "mg3d_smooth"));
     if (iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_smooth: negative iteration count");
@@ -715,6 +750,7 @@ extern "C" int mg3d_smooth(mg3d_ctx *ctx, int level, int post, int iters)
 
 extern "C" int mg3d_residual(mg3d_ctx *ctx, int level, int store, double *norm)
 {
+    mg3d_drop_carry(ctx);
     CHK(check_field_level(ctx, 0, level, "mg3d_residual"));
     CHK(enqueue_residual(ctx, level, store, 0));
     CHK(launch_ok("mg3d_residual"));
@@ -723,6 +759,7 @@ extern "C" int mg3d_residual(mg3d_ctx *ctx, int level, int store, double *norm)
 
 extern "C" int mg3d_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters, int store, double *norm)
 {
+    mg3d_drop_carry(ctx);
     CHK(check_field_level(ctx, 0, level, "mg3d_smooth_residual"));
     if (iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_smooth_residual: negative iteration count");
@@ -733,6 +770,7 @@ extern "C" int mg3d_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
 
 extern "C" int mg3d_smooth_restrict(mg3d_ctx *ctx, int level, int iters)
 {
+    mg3d_drop_carry(ctx);
     CHK(check_field_level(ctx, 0, level, "mg3d_smooth_restrict"));
     if (level < 1 || iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_smooth_restrict: bad level/iteration count");
@@ -745,6 +783,7 @@ extern "C" int mg3d_smooth_restrict(mg3d_ctx *ctx, int level, int iters)
 
 extern "C" int mg3d_restrict(mg3d_ctx *ctx, int level)
 {
+    mg3d_drop_carry(ctx);
     CHK(check_field_level(ctx, 0, level, "mg3d_restrict"));
     if (level < 1)
         return fail(MG3D_ERR_ARG, "mg3d_restrict: level 0 has no coarser level");
@@ -755,6 +794,7 @@ extern "C" int mg3d_restrict(mg3d_ctx *ctx, int level)
 
 extern "C" int mg3d_prolong(mg3d_ctx *ctx, int level)
 {
+    mg3d_drop_carry(ctx);
     CHK(check_field_level(ctx, 0, level, "mg3d_prolong"));
     if (level < 1)
         return fail(MG3D_ERR_ARG, "mg3d_prolong: level 0 has no coarser level");
@@ -765,6 +805,7 @@ extern "C" int mg3d_prolong(mg3d_ctx *ctx, int level)
 
 extern "C" int mg3d_coarse_solve(mg3d_ctx *ctx)
 {
+    mg3d_drop_carry(ctx);
     if (!ctx)
         return fail(MG3D_ERR_ARG, "mg3d_coarse_solve: NULL context");
     if (!ctx->have_lu)
@@ -777,6 +818,7 @@ extern "C" int mg3d_coarse_solve(mg3d_ctx *ctx)
 
 extern "C" int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm)
 {
+    mg3d_drop_carry(ctx);
     CHK(check_field_level(ctx, field, level, "mg3d_l2norm"));
     k_sumsq(ctx->lv[level].g, ctx->lv[level].f[field], ctx->partials, ctx->sumsq, ctx->stream);
     CHK(launch_ok("mg3d_l2norm"));
@@ -786,7 +828,28 @@ extern "C" int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm)
 /* ------------------------------------------------------------------ V-cycle */
 /* vcycle, mg_3d.h:1242-1362, unrolled: descend q..1, solve level 0, ascend 1..q.
  * The squared post-smoothing norm of level q goes to sumsq[slot]. */
-int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
+/* Carried cycles.  Back to back, V-cycle n ends with post-smoothing passes black, red, black, red and the residual norm,
+ * and cycle n+1 begins with pre-smoothing passes red, black, red, black on the same u and d (mg_3d.h:728 / :657).  That
+ * first red pass recomputes every red point from black neighbours no pass has touched since the red pass before it: the
+ * same operands in the same expression, the same bits -- it is the identity.  What is left is ONE alternating run
+ *      [prolongation] B R | B R <norm of cycle n> B R | B [residual, restriction]
+ * which three launches cover instead of four: prolongation + 2 passes (as before), four passes with the norm tapped
+ * after the second (k_sweep_tap: no stage of its own), one pass + residual + restriction -- 9 n w + 2 n_c w instead of
+ * 11 n w + 2 n_c w compulsory bytes per cycle on the top level.  The tap launch reads u of cycle n and writes the other
+ * buffer; cycle n's own u (the tapped state) is never written -- mg3d_drop_carry makes it from that input when it is
+ * wanted.  mg3d_vcycles never ends a call in the carried state (its last cycle ends the ordinary way); mg3d_vcycle does.  Only V(2,2) from the finest level of a context with
+ * at least three levels, fused sweeps, r not kept; MG3D_NO_CARRY=1 switches it off (tests compare both). */
+bool mg3d_can_carry(const mg3d_ctx *ctx, int q)
+{
+    const char *e = getenv("MG3D_NO_CARRY"); /* read per call: tests toggle it */
+    if (e && e[0] == '1')
+        return false;
+    return ctx->fused && !ctx->keep_r && !ctx->have_es && ctx->iters == 2 && q == ctx->L - 1 && q >= 2 &&
+           ctx->lv[q].g.N > k_sweep_small_max() && (ctx->lv[q].g.nj & 1) != 0 && split_up_leg(2, 1) &&
+           pro_fusable(ctx, 2, 1, q);
+}
+
+int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, bool carry_out)
 {
     if (!ctx->have_lu)
         return fail(MG3D_ERR_STATE, "mg3d_vcycle: no coarse LU set (mg3d_ctx_build_coarse / mg3d_ctx_set_lu)");
@@ -811,8 +874,36 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
      * factor exists (mg3d_tiny.hip, tiny_cycle_kernel); MG3D_NO_TINY_CYCLE=1 keeps the three launches (tests compare) */
     const bool no_cyc = getenv("MG3D_NO_TINY_CYCLE") && getenv("MG3D_NO_TINY_CYCLE")[0] == '1';
     const bool tiny_cyc = tiny && !no_cyc && k_tiny_cycle_fits(ctx->lv[1].g, ctx->lv[0].g, ctx->lu, ctx->lu_in);
+    const bool can_carry = mg3d_can_carry(ctx, q);
+    const bool carry_in = ctx->carried;
+    if (carry_in && !can_carry) { /* (cannot happen through the entry points: they drop the state first) */
+        drop_carry(ctx);
+        return fail(MG3D_ERR_STATE, "mg3d_vcycle: carried state met a cycle that cannot continue it");
+    }
+    ctx->carried = false;
     for (int l = q; l >= 1; l--) {
         Level &lev = ctx->lv[l];
+        if (l == q && carry_in) {
+            { /* the one pre-smoothing pass that is left (black) + residual + restriction (:1282 + :1294 + :1310) */
+                StageScope t(ctx, l, MG3D_ST_SMOOTH1);
+                StageScope kt(ctx, l, MG3D_K_SWEEP1_RESTRICT, true);
+                const int np = k_sweep(lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, nullptr, nullptr, MG3D_MAX_PARTIALS, lev.h,
+                                       1, 0, true, s, 0, -1, &ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_D]);
+                if (np < 0)
+                    return fail(MG3D_ERR_STATE, "carried cycle: no kernel for one pass + residual + restriction");
+                double *t2 = lev.f[MG3D_U];
+                lev.f[MG3D_U] = lev.alt;
+                lev.alt = t2;
+            }
+            { StageScope t(ctx, l, MG3D_ST_RESIDUAL1); }
+            StageScope t(ctx, l, MG3D_ST_RESTRICT);
+            if (ctx->faces_dirty[l] || ctx->faces_always[l]) {
+                StageScope kt(ctx, l, MG3D_K_RESTRICT, true);
+                k_restrict(lev.g, lev.f[MG3D_R], ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_D], s, -1, -1, true);
+                ctx->faces_dirty[l] = 0;
+            }
+            continue;
+        }
         if (l == 1 && tiny_cyc) {
             {
                 StageScope t(ctx, l, MG3D_ST_SMOOTH1);
@@ -899,6 +990,28 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot)
             { StageScope t(ctx, l, MG3D_ST_RESIDUAL2); }
             continue;
         }
+        if (l == q && carry_out && can_carry) {
+            { StageScope t(ctx, l, MG3D_ST_PROLONG); } /* :1331, folded into the launch below */
+            {
+                StageScope t(ctx, l, MG3D_ST_SMOOTH2);
+                /* prolongation + the first two post-smoothing passes: the launch the ordinary cycle starts its up-leg with */
+                CHK(enqueue_smooth_residual(ctx, l, 1, 1, 0, slot, nullptr, &ctx->lv[l - 1]));
+                /* black, red (:1341, second half) <norm, :1354> black, red (:1282 of the next cycle, its first red pass
+                 * being the identity) */
+                StageScope kt(ctx, l, MG3D_K_SWEEP4_NORM, true);
+                const int np = k_sweep_tap(lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, ctx->partials, MG3D_MAX_PARTIALS,
+                                           lev.h, 0, s);
+                if (np < 0)
+                    return fail(MG3D_ERR_STATE, "carried cycle: no kernel for four passes + norm tap");
+                double *t2 = lev.f[MG3D_U];
+                lev.f[MG3D_U] = lev.alt;
+                lev.alt = t2;
+                k_fold(ctx->partials, np, ctx->sumsq + slot, s);
+                ctx->carried = true;
+            }
+            { StageScope t(ctx, l, MG3D_ST_RESIDUAL2); }
+            continue;
+        }
         const int want_norm = l == q ? 1 : 0;
         const bool pro = pro_fusable(ctx, ctx->iters, want_norm, l);
         {
@@ -939,7 +1052,17 @@ extern "C" int mg3d_vcycle(mg3d_ctx *ctx, int level, double *norm)
             *norm = 0.;
         return MG3D_OK;
     }
-    CHK(mg3d_enqueue_vcycle(ctx, level, 0));
+    if (level != ctx->L - 1)
+        drop_carry(ctx);
+    /* One cycle per call is how the reference's solve loop runs (SolverLinSolve, mg_3d.h:1415-1420): the call ends with
+     * the launch that also begins the NEXT cycle -- speculatively; whatever the caller does instead of another cycle
+     * first puts the finished cycle's own u back (mg3d_drop_carry), and the norm returned is this cycle's either way.
+     * Not once a raw pointer to u or d of the top level is out (mg3d_ctx_touched). */
+    const int rc = mg3d_enqueue_vcycle(ctx, level, 0, !ctx->raw_top);
+    if (rc != MG3D_OK) {
+        drop_carry(ctx);
+        return rc;
+    }
     return read_norm(ctx, 0, norm);
 }
 
@@ -957,10 +1080,16 @@ extern "C" int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms)
         return mg3d_sync(ctx);
     }
     const int batch = ctx->sumsq_slots - 1;
+    if (count == 0) /* (behind a single mg3d_vcycle call the first cycle continues from the carried state) */
+        drop_carry(ctx);
+    struct Guard { /* an error return must not leave u of the top level a few passes into a cycle nobody asked for */
+        mg3d_ctx *c;
+        ~Guard() { drop_carry(c); }
+    } guard{ctx};
     for (int done = 0; done < count;) {
         const int nb = (count - done < batch) ? count - done : batch;
         for (int c = 0; c < nb; c++)
-            CHK(mg3d_enqueue_vcycle(ctx, q, c));
+            CHK(mg3d_enqueue_vcycle(ctx, q, c, done + c + 1 < count)); /* every cycle but the last carries into the next */
         HIPCHK(hipMemcpyAsync(ctx->h_sumsq, ctx->sumsq, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         resolve_timers(ctx);
@@ -975,6 +1104,7 @@ extern "C" int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms)
 /* -------------------------------------------------------------------- FMG */
 extern "C" int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level)
 {
+    mg3d_drop_carry(ctx);
     CHK(check_field_level(ctx, field, level, "mg3d_fill_boundary"));
     k_fill_boundary(ctx->lv[level].g, ctx->lv[level].f[field], ctx->lv[level].h, ctx->stream);
     mg3d_ctx_touched(ctx, field, level);
@@ -984,6 +1114,7 @@ extern "C" int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level)
 /* SolverFMGInitialize, mg_dirichlet_analytic.c:771-806 */
 extern "C" int mg3d_fmg_initialize(mg3d_ctx *ctx)
 {
+    mg3d_drop_carry(ctx);
     if (!ctx)
         return fail(MG3D_ERR_ARG, "mg3d_fmg_initialize: NULL context");
     if (!ctx->have_lu)

@@ -68,6 +68,7 @@ void k_fold(const double *partials, int np, double *out, hipStream_t s);
  * receives it on the interior, partials (may be NULL) one sum of diff^2 per block.  Returns the number
  * of partials written (>= 0) or -1 when the (S, residual) shape has no instantiation. */
 void k_sweep_set_tune_default(int on); /* first-use chunk measurement on / off unless MG3D_SWEEP_TUNE says otherwise */
+int k_sweep_small_max(); /* MG3D_SMALL_MAX: largest level side that runs the two-rows-per-thread shapes (default 65) */
 int k_sweep_fuse_leg_max(); /* MG3D_FUSE_LEG_MAX: largest level side whose legs run as one launch each (default 65) */
 bool k_sweep_fuse_rst2(); /* opt-in (MG3D_FUSE_RST2=1): two passes + residual + restriction as ONE launch */
 int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
@@ -80,6 +81,11 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
             trilinear prolongation of the coarse field ec (smoothing-only launches, S = 2 or 4) */,
             int i_lo = -1, int i_hi = -1 /* local output planes of this launch; default all.  Several launches
             with disjoint windows and the same vin/vout make up one sweep (overlap with halo exchange) */);
+/* FOUR colour passes starting with colour c1 and, into partials, the residual norm of the state after the SECOND one
+ * (the launch that ends one V-cycle -- its last two post-smoothing passes and its norm -- and begins the next: mg3d_ctx.hip,
+ * "carried cycles").  Returns the number of partials written or -1. */
+int k_sweep_tap(const Geom &g, const double *vin, const double *d, double *vout, double *partials, int max_partials,
+                double h, int c1, hipStream_t s, int acc_lo = 0, int acc_hi = -1);
 /* mg3d_tiny.hip: the level above the coarsest one in one workgroup (LDS-resident), when it fits (N <= 17) */
 bool k_tiny_fits(const Geom &g, const Geom &gc);
 /* zero guess, `iters` x (red, black), residual, restriction (interior + face injection from r's boundary) into dc */

@@ -86,16 +86,20 @@ struct SweepArgs {
 };
 
 /* RES: 0 = smoothing only, 1 = + residual (r store and/or norm), 2 = + residual AND full-weighting
- * restriction of it into the coarse right-hand side (mg_3d.h:961-995) -- r never travels to HBM.
+ * restriction of it into the coarse right-hand side (mg_3d.h:961-995) -- r never travels to HBM;
+ * 3 = the residual NORM of the state half-way through the passes (after pass S/2), see "tap" in the kernel.
  * The 27-point restriction stencil reaches one fine point beyond the coarse point's centre, so its halo
  * and warm-up are one deeper. */
 template <int S, int RES> struct SweepShape {
     /* With S > 0 the residual of the colour updated last falls out of stage S itself (same neighbour
      * sum), the other colour needs one more gather: ST = S + 1.  A pure residual (S == 0) needs both. */
-    static constexpr int ST = S + (RES ? (S > 0 ? 1 : 2) : 0); /* pipeline stages */
-    static constexpr int HJ = S + (RES ? 1 : 0) + (RES == 2 ? 1 : 0); /* halo rows */
+    static constexpr bool TAIL = RES == 1 || RES == 2; /* a residual BEHIND the passes (the tap costs no stage) */
+    static constexpr int ST = S + (TAIL ? (S > 0 ? 1 : 2) : 0); /* pipeline stages */
+    /* halo rows; even where the restriction rides along: its coarse rows are centred on a thread's EVEN rows, so a tile's
+     * first row must be an even row of the level (one pass + residual + restriction: 4, not 3) */
+    static constexpr int HJ = RES == 2 ? ((S + 2 + 1) & ~1) : S + (TAIL ? 1 : 0);
     static constexpr int HK = (HJ + 1) & ~1;     /* halo columns, even so pairs stay aligned */
-    static constexpr int HI = S + (RES ? 1 : 0) + (RES == 2 ? 1 : 0); /* warm-up planes */
+    static constexpr int HI = S + (TAIL ? 1 : 0) + (RES == 2 ? 1 : 0); /* warm-up planes */
 };
 
 /* One-lane shifts across the whole wave as DPP moves (v_mov_b32_dpp wave_shr:1 / wave_shl:1, two per
@@ -177,6 +181,12 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
     /* PRO: three consecutive coarse planes of the tile's coarse footprint, [plane % 3][row][col] */
     constexpr int CRW = PRO ? (NW * RJ) / 2 + 2 : 1, CCW = PRO ? WAVE + 2 : 1;
     __shared__ double cpl[PRO ? 3 : 1][CRW][CCW];
+    /* RES == 2 behind colour passes: the r pairs a thread hands from one step's rows to the next step's restriction are
+     * written once and read once a whole step later -- parked in LDS (own rows only: no hazard, no second buffer) they
+     * free 4 x RJ VGPRs of a shape that otherwise spills inside the plane loop */
+    constexpr bool RPARK = RES == 2 && S > 0 && RJ >= 4;
+    __shared__ double2 rpark[RPARK ? NW * RJ : 1][RPARK ? WAVE : 1];
+    __shared__ double rkpark[RPARK ? NW * RJ : 1][RPARK ? WAVE : 1]; /* likewise the diff a row keeps for one step (rkeep) */
 
     const Geom &g = a.g;
     /* the wave index through readfirstlane: the compiler then knows that everything derived from it (the row
@@ -304,7 +314,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 #ifndef MG3D_ADDR32
 #define MG3D_ADDR32 3 /* same bits: 32-bit per-lane offsets instead of 64-bit ones */
 #endif
-    constexpr int SHAPE_BIT = (S == 4 && RES == 0) ? 0 : 1;
+    constexpr int SHAPE_BIT = (S == 4 && (RES == 0 || RES == 3)) ? 0 : 1;
     constexpr int DLAG = (MG3D_DLAG >> SHAPE_BIT) & 1;
     constexpr bool A32 = ((MG3D_ADDR32 >> SHAPE_BIT) & 1) != 0;
     typename std::conditional<A32, unsigned, long long>::type row_off[RJ];
@@ -357,11 +367,14 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         rkeep[rr] = 0.;
         cur_v[rr] = make_double2(0., 0.);
     }
-    double2 rcur[RJ], rlag[RJ]; /* RES == 2: r pairs of the plane finished this step / the step before */
+    double2 rlag[RJ];           /* RES == 2: r pairs of the plane finished by the previous step */
     double racc[RJ / 2];        /* running 27-point sums, one per coarse row centred in this thread's rows */
 #pragma unroll
-    for (int rr = 0; rr < RJ; rr++)
-        rcur[rr] = rlag[rr] = make_double2(0., 0.);
+    for (int rr = 0; rr < RJ; rr++) {
+        rlag[rr] = make_double2(0., 0.);
+        if constexpr (RPARK)
+            rpark[w * RJ + rr][lane] = make_double2(0., 0.), rkpark[w * RJ + rr][lane] = 0.;
+    }
 #pragma unroll
     for (int c = 0; c < RJ / 2; c++)
         racc[c] = 0.;
@@ -370,7 +383,12 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
      * i - s, s >= 1), so its load trails u's by one step and lands straight in the first slot of the d window -- one
      * slot (2 x RJ doubles: 16 VGPRs of a register file that every shape fills) less than loading both together */
     auto load_plane = [&](int i, double2(&vv)[RJ], double2(&dd)[RJ]) {
+#ifdef MG3D_EXPERIMENT_SAME_PLANE /* timing experiment only (wrong results): every load hits the same, cached, plane */
+        const int iu = i_s < 0 ? 0 : i_s, id = iu;
+        (void)i;
+#else
         const int iu = i < 0 ? 0 : (i >= g.ni ? g.ni - 1 : i), id = i - DLAG < 0 ? 0 : (i - DLAG >= g.ni ? g.ni - 1 : i - DLAG);
+#endif
         /* plane bases in bytes, uniform: one scalar 64-bit product per plane, not one re-materialised per row */
         long long pbase = (long long)((unsigned long long)plane_bytes * (unsigned)iu), pbase_d = (long long)((unsigned long long)plane_bytes * (unsigned)id);
         asm volatile("" : "+s"(pbase), "+s"(pbase_d));
@@ -463,18 +481,49 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         const int i = i_s + pl; /* local plane just arrived */
         const int par = pl & 1;
         /* current plane <- head of the prefetch queue, then request plane i+PF */
+#ifndef MG3D_PIN_LOADS
+#define MG3D_PIN_LOADS 0
+#endif
+        if constexpr (MG3D_PIN_LOADS != 0) {
+            /* The plane requested a step ago is first TOUCHED here, behind the barrier: an empty volatile asm that takes its
+             * registers.  Without it the scheduler hoists this step's first copies of those registers (plain VALU moves,
+             * free to cross an s_barrier) into the tail of the previous step, and the wait for the load goes with them:
+             * the listing showed `s_waitcnt vmcnt(7) .. (4)` strung through the step that had just issued the request --
+             * a plane was in flight for a fraction of a step, not for one. */
+            constexpr int SLOT = PF == 2 ? PAR : 0;
 #pragma unroll
-        for (int rr = 0; rr < RJ; rr++) {
-            cur_v[rr] = nxt_v[0][rr];
-            dring[rr][0][0] = nxt_d[0][rr].x;
-            dring[rr][0][1] = nxt_d[0][rr].y;
-#pragma unroll
-            for (int f = 0; f + 1 < PF; f++) {
-                nxt_v[f][rr] = nxt_v[f + 1][rr];
-                nxt_d[f][rr] = nxt_d[f + 1][rr];
-            }
+            for (int rr = 0; rr < RJ; rr++)
+                asm volatile("" : "+v"(nxt_v[SLOT][rr].x), "+v"(nxt_v[SLOT][rr].y), "+v"(nxt_d[SLOT][rr].x), "+v"(nxt_d[SLOT][rr].y));
         }
-        load_plane(i + PF, nxt_v[PF - 1], nxt_d[PF - 1]);
+        if constexpr (PF == 2) {
+            /* two planes in flight as a RING indexed by the step's parity (a template argument), not a queue that shifts:
+             * shifting copies the registers of the plane still in flight, and a copy has to wait for its load -- with
+             * the queue a "second plane in flight" was never in flight for more than one step */
+#pragma unroll
+            for (int rr = 0; rr < RJ; rr++) {
+                cur_v[rr] = nxt_v[PAR][rr];
+                dring[rr][0][0] = nxt_d[PAR][rr].x;
+                dring[rr][0][1] = nxt_d[PAR][rr].y;
+            }
+#ifndef MG3D_PF2_LATE
+#define MG3D_PF2_LATE 0 /* 1: the ring's loads are issued at the END of the step, behind its stores (see there) */
+#endif
+            if constexpr (MG3D_PF2_LATE == 0)
+                load_plane(i + PF, nxt_v[PAR], nxt_d[PAR]);
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < RJ; rr++) {
+                cur_v[rr] = nxt_v[0][rr];
+                dring[rr][0][0] = nxt_d[0][rr].x;
+                dring[rr][0][1] = nxt_d[0][rr].y;
+#pragma unroll
+                for (int f = 0; f + 1 < PF; f++) {
+                    nxt_v[f][rr] = nxt_v[f + 1][rr];
+                    nxt_d[f][rr] = nxt_d[f + 1][rr];
+                }
+            }
+            load_plane(i + PF, nxt_v[PF - 1], nxt_d[PF - 1]);
+        }
         double cbuf[CPT];
         bool stage_new = false;
         if constexpr (PRO) {
@@ -549,15 +598,65 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         for (int s = 1; s <= ST; s++) {
             const int q = i - s;
             pl_upd[s] = (unsigned)(q - upd_lo) <= upd_span;
-            acc_ok[s] = RES == 1 ? (unsigned)(q - nrm_lo) <= nrm_span : false; /* planes that enter the norm */
+            acc_ok[s] = (RES == 1 || RES == 3) ? (unsigned)(q - nrm_lo) <= nrm_span : false; /* planes that enter the norm */
         }
         /* this step's store planes lie in the output range (wave-uniform, once per step, not once per row) */
         const bool v_ok = (unsigned)(i - S - i_out0) < (unsigned)len;
         const bool r_ok = RES == 1 ? (a.r != nullptr) & ((unsigned)(i - ST - i_out0) < (unsigned)len) & pl_upd[ST] : false;
 /* wave-uniform tests joined without short-circuit where that is free (one scalar AND instead of a branch per operand);
  * the restriction shape spills with it (scratch 36 -> 96 bytes, 0.59 -> 1.0 ms), the pure smoothers gain nothing */
-#define MG3D_AND(x, y) (RES == 1 ? ((x) & (y)) : ((x) && (y)))
+#define MG3D_AND(x, y) ((RES == 1 || RES == 3) ? ((x) & (y)) : ((x) && (y)))
 
+        if constexpr (RES == 2) {
+            /* (BEFORE this step's rows: they overwrite rlag in place -- a second set of r pairs would be 4 x RJ VGPRs)
+             * Full weighting of plane qq = i-ST-1 (its r pairs are in rlag; the row above this wave's first
+             * row was published by the wave above at the end of the previous step).  Coarse row centres sit
+             * on this thread's even rows rr = 0, 2, ..; coarse column = this lane's even column kA.  The
+             * reference adds the 27 products r*w in the order ti, tj, tk (mg_3d.h:980-988): planes arrive
+             * in ti order, and inside a plane the nine terms below are tj-major, tk-minor. */
+            const int qq = i - ST - 1, qg = g.ig0 + qq;
+            const bool odd = (qg & 1) != 0;
+            const double wi = odd ? 0.25 : 0.5;
+            const double2 top = rex[par ^ 1][w > 0 ? w - 1 : 0][lane]; /* wave 0: a halo row's sum, never stored */
+#pragma unroll
+            for (int c = 0; c < RJ / 2; c++) {
+                double2 r0, r1, r2;
+                if constexpr (RPARK) {
+                    r0 = c == 0 ? top : rpark[w * RJ + 2 * c - 1][lane];
+                    r1 = rpark[w * RJ + 2 * c][lane];
+                    r2 = rpark[w * RJ + 2 * c + 1][lane];
+                } else {
+                    r0 = c == 0 ? top : rlag[2 * c - 1];
+                    r1 = rlag[2 * c];
+                    r2 = rlag[2 * c + 1];
+                }
+                const double l0 = lane_from_left(r0.y), l1 = lane_from_left(r1.y), l2 = lane_from_left(r2.y);
+                const double p[9] = {l0 * (wi * 0.25 * 0.25), r0.x * (wi * 0.25 * 0.5), r0.y * (wi * 0.25 * 0.25),
+                                     l1 * (wi * 0.5 * 0.25),  r1.x * (wi * 0.5 * 0.5),  r1.y * (wi * 0.5 * 0.25),
+                                     l2 * (wi * 0.25 * 0.25), r2.x * (wi * 0.25 * 0.5), r2.y * (wi * 0.25 * 0.25)};
+                double run = racc[c];
+#pragma unroll
+                for (int t = 0; t < 9; t++)
+                    run = run + p[t];
+                if (odd) {
+                    /* qq is the ti = 2 plane of coarse plane (qg-1)/2 and the ti = 0 plane of (qg+1)/2.  The coarse plane
+                     * is stored when its centre plane qq - 1 lies in this segment's output range, it is an interior
+                     * plane of the coarse level and one this launch is to write: one range of qq (rst_lo, rst_span) */
+                    if (((unsigned)(qq - rst_lo) <= rst_span) & crow_ok[c]) { /* wave-uniform */
+                        const int icl = ((qg - 1) >> 1) - a.gc.ig0;
+                        if (ccol_ok)
+                            a.dc[a.gc.plane * icl + dc_off[c]] = run;
+                    }
+                    double fresh = 0.;
+#pragma unroll
+                    for (int t = 0; t < 9; t++)
+                        fresh = fresh + p[t];
+                    racc[c] = fresh;
+                } else {
+                    racc[c] = run;
+                }
+            }
+        }
 #pragma unroll
         for (int rr = 0; rr < RJ; rr++) {
             const int X = (PAR + rr) & 1; /* active column of this row at this step */
@@ -589,9 +688,25 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                  * it (78 branches a step); the select costs nothing and leaves one basic block to schedule */
                 const bool updu = row_upd[rr] & pl_upd[s]; /* wave-uniform part of "this point is updated" */
                 if (s <= S) {
+#ifdef MG3D_EXPERIMENT_DROP_FLOPS /* timing experiment only (wrong results): is the step bound by its fp64 operations? */
+                    const double val = sum - dd;
+#else
                     const double val = a.sixth * (sum - a.hSq * dd); /* mg_3d.h:438-443 */
+#endif
                     nw[s] = (updu & col_upd[X]) ? val : center;
-                    if (RES && s == S) { /* residual of the point just updated: same six neighbours */
+                    if constexpr (RES == 3) {
+                        /* The tap: the residual norm of the state BETWEEN pass S/2 and pass S/2 + 1 without a stage of its
+                         * own.  The colour pass S/2 has just updated: its residual uses that pass's neighbour sum (as
+                         * below).  The other colour: pass S/2 + 1 is about to update it from exactly the six neighbours
+                         * (all of the colour pass S/2 + 1 leaves alone) and the centre (untouched by pass S/2) that the
+                         * residual of the tapped state is made of -- mg_3d.h:819-821 on the sum the update forms anyway. */
+                        if (s == S / 2 || s == S / 2 + 1) {
+                            const double diff = dd - a.invHsq * (sum - 6 * (s == S / 2 ? nw[s] : center));
+                            if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
+                                acc += own_upd[X] ? diff * diff : 0.;
+                        }
+                    }
+                    if ((RES == 1 || RES == 2) && s == S) { /* residual of the point just updated: same six neighbours */
                         const double diff = dd - a.invHsq * (sum - 6 * nw[s]); /* mg_3d.h:819-821 */
                         diffs[0] = diff;
                         /* adding +0 leaves a sum of squares unchanged: a select, not a branch */
@@ -622,9 +737,17 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
             if constexpr (RES == 2 || (RES == 1 && RST)) { /* RST = false: the norm only, r is not assembled */
                 /* column X: the residual-only stage now; column X^1: the previous step's diff */
                 double2 o;
-                o.x = X ? rkeep[rr] : diffs[1];
-                o.y = X ? diffs[1] : rkeep[rr];
-                rcur[rr] = o;
+                const double kept = RPARK ? rkpark[w * RJ + rr][lane] : rkeep[rr];
+                o.x = X ? kept : diffs[1];
+                o.y = X ? diffs[1] : kept;
+                if constexpr (RES == 2) { /* read by the NEXT step's restriction */
+                    if constexpr (RPARK)
+                        rpark[w * RJ + rr][lane] = o;
+                    else
+                        rlag[rr] = o;
+                    if (rr == RJ - 1)
+                        rex[par][w][lane] = o;
+                }
                 if (RES == 1 && MG3D_AND(MG3D_AND(r_ok, row_own[rr]), row_upd[rr])) { /* wave-uniform */
                     double *dst = reinterpret_cast<double *>(reinterpret_cast<char *>(a.r) + rbase + row_off[rr]);
                     if (own_both)
@@ -636,7 +759,10 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                             dst[1] = o.y;
                     }
                 }
-                rkeep[rr] = diffs[0];
+                if constexpr (RPARK)
+                    rkpark[w * RJ + rr][lane] = diffs[0];
+                else
+                    rkeep[rr] = diffs[0];
             }
             /* ---- commit this row's new outputs */
             in_prev[rr][0] = cur_v[rr].x;
@@ -644,50 +770,6 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
 #pragma unroll
             for (int s = 0; s < ST; s++)
                 last[rr][s][X] = nw[s];
-        }
-        if constexpr (RES == 2) {
-            /* Full weighting of plane qq = i-ST-1 (its r pairs are in rlag; the row above this wave's first
-             * row was published by the wave above at the end of the previous step).  Coarse row centres sit
-             * on this thread's even rows rr = 0, 2, ..; coarse column = this lane's even column kA.  The
-             * reference adds the 27 products r*w in the order ti, tj, tk (mg_3d.h:980-988): planes arrive
-             * in ti order, and inside a plane the nine terms below are tj-major, tk-minor. */
-            const int qq = i - ST - 1, qg = g.ig0 + qq;
-            const bool odd = (qg & 1) != 0;
-            const double wi = odd ? 0.25 : 0.5;
-            const double2 top = rex[par ^ 1][w > 0 ? w - 1 : 0][lane]; /* wave 0: a halo row's sum, never stored */
-#pragma unroll
-            for (int c = 0; c < RJ / 2; c++) {
-                const double2 r0 = c == 0 ? top : rlag[2 * c - 1], r1 = rlag[2 * c], r2 = rlag[2 * c + 1];
-                const double l0 = lane_from_left(r0.y), l1 = lane_from_left(r1.y), l2 = lane_from_left(r2.y);
-                const double p[9] = {l0 * (wi * 0.25 * 0.25), r0.x * (wi * 0.25 * 0.5), r0.y * (wi * 0.25 * 0.25),
-                                     l1 * (wi * 0.5 * 0.25),  r1.x * (wi * 0.5 * 0.5),  r1.y * (wi * 0.5 * 0.25),
-                                     l2 * (wi * 0.25 * 0.25), r2.x * (wi * 0.25 * 0.5), r2.y * (wi * 0.25 * 0.25)};
-                double run = racc[c];
-#pragma unroll
-                for (int t = 0; t < 9; t++)
-                    run = run + p[t];
-                if (odd) {
-                    /* qq is the ti = 2 plane of coarse plane (qg-1)/2 and the ti = 0 plane of (qg+1)/2.  The coarse plane
-                     * is stored when its centre plane qq - 1 lies in this segment's output range, it is an interior
-                     * plane of the coarse level and one this launch is to write: one range of qq (rst_lo, rst_span) */
-                    if (((unsigned)(qq - rst_lo) <= rst_span) & crow_ok[c]) { /* wave-uniform */
-                        const int icl = ((qg - 1) >> 1) - a.gc.ig0;
-                        if (ccol_ok)
-                            a.dc[a.gc.plane * icl + dc_off[c]] = run;
-                    }
-                    double fresh = 0.;
-#pragma unroll
-                    for (int t = 0; t < 9; t++)
-                        fresh = fresh + p[t];
-                    racc[c] = fresh;
-                } else {
-                    racc[c] = run;
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < RJ; rr++)
-                rlag[rr] = rcur[rr];
-            rex[par][w][lane] = rcur[RJ - 1];
         }
         /* age the d window (slots 0 .. ST-1 = planes i-1 .. i-ST) */
 #pragma unroll
@@ -697,6 +779,13 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
                 dring[rr][s][0] = dring[rr][s - 1][0];
                 dring[rr][s][1] = dring[rr][s - 1][1];
             }
+        /* PF == 2: request plane i + 2 now, BEHIND this step's stores.  vmcnt counts loads and stores in issue order:
+         * with the request at the top of the step the compiler's wait for the plane the NEXT step needs also covers this
+         * step's younger stores and, piecemeal, the request itself -- a plane was never in flight for a whole step.  Issued
+         * last, the only operations younger than the plane a step waits for are one step's stores and one request:
+         * the wait (vmcnt(12)) leaves exactly that request in flight. */
+        if constexpr (PF == 2 && MG3D_PF2_LATE != 0)
+            load_plane(i + PF, nxt_v[PAR], nxt_d[PAR]);
         /* publish this wave's edge rows for the next step */
 #pragma unroll
         for (int s = 0; s < ST; s++) {
@@ -721,7 +810,7 @@ __global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
         step(pl, std::integral_constant<int, 0>{});
     } /* segments */
 
-    if (RES == 1 && a.partials) {
+    if ((RES == 1 || RES == 3) && a.partials) {
 #pragma unroll
         for (int off = WAVE / 2; off > 0; off >>= 1)
             acc += __shfl_down(acc, off, WAVE);
@@ -807,7 +896,7 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
         /* the four-pass launch saturates the memory system with ~80 % of the CUs streaming; the shorter pipelines
          * (two passes + residual, residual + restriction, prolongation + two passes) spend more of a step computing
          * and keep scaling to all of them */
-        const double sat = S >= 4 && RES == 0 ? 0.8 : 1.0;
+        const double sat = S >= 4 && (RES == 0 || RES == 3) ? 0.8 : 1.0;
         const double crit = (double)((blocks + ncu - 1) / ncu) * steps, bw = (double)blocks * steps / (sat * ncu);
         return crit > bw ? crit : bw;
     };
@@ -844,7 +933,7 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
     const char *te = getenv("MG3D_SWEEP_TAIL"); /* 0: never, 1: whenever it is shorter; unset: four passes at 4 turns */
     const int tail_mode = te ? atoi(te) : 2;
     a.CI = best_ci;
-    if (tail_ci && (tail_mode == 1 || (tail_mode == 2 && S >= 4 && RES == 0 && ((int)T + (ncu % (int)T) - 1) / (ncu % (int)T) >= 4)))
+    if (tail_ci && (tail_mode == 1 || (tail_mode == 2 && S >= 4 && (RES == 0 || RES == 3) && ((int)T + (ncu % (int)T) - 1) / (ncu % (int)T) >= 4)))
         a.CI = tail_ci;
     bool forced = false;
     char ci_shape[32]; /* MG3D_SWEEP_CI: every shape; MG3D_SWEEP_CI_<S><RES>[P]: one shape (e.g. _02 residual + restriction) */
@@ -1044,6 +1133,18 @@ template <> int dispatch<2, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
     TRY(2, 2, 4, 8, 1)
     DFLT(2, 2, 4, 8, 1)
 }
+template <> int dispatch<1, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+{
+    /* the LAST pre-smoothing pass + residual + restriction: the down-leg's only launch on the top level of a cycle whose
+     * first three pre-smoothing passes rode on the previous cycle's last launch (k_sweep_tap) */
+    TRY(1, 2, 4, 8, 1) TRY(1, 2, 4, 8, 2)
+    DFLT(1, 2, 4, 8, 1)
+}
+template <> int dispatch<4, 3>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+{
+    TRY(4, 3, 4, 8, 1)
+    DFLT(4, 3, 4, 8, 1)
+}
 
 int k_sweep_small_max() /* levels of at most this many points per side use the two-rows-per-thread shapes */
 {
@@ -1066,9 +1167,10 @@ bool k_sweep_fuse_rst2() /* MG3D_FUSE_RST2=1: keep the one-launch shape for two 
     return e && e[0] == '1';
 }
 
-int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
-            int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo, int acc_hi,
-            const Geom *gc, double *dc, int ic_lo, int ic_hi, const Geom *gce, const double *ec, int i_lo, int i_hi)
+static int sweep_impl(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
+                      int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo, int acc_hi,
+                      const Geom *gc, double *dc, int ic_lo, int ic_hi, const Geom *gce, const double *ec, int i_lo, int i_hi,
+                      bool tap)
 {
     SweepArgs a;
     a.i_lo = i_lo >= 0 ? i_lo : 0;
@@ -1103,6 +1205,11 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
     a.sixth = 1. / 6;        /* mg_3d.h:646 */
     a.invHsq = 1. / (h * h); /* mg_3d.h:797 */
     a.c1 = c1;
+    if (tap) { /* four passes, the residual norm of the state after the second one into partials */
+        if (S != 4 || dc || ec || r || !partials || residual)
+            return -1;
+        return dispatch<4, 3>(a, env_cfg({4, 8, 1}), max_partials, s);
+    }
     if (ec) { /* prolongation fused into the input: 4- and 2-pass smoothing launches */
         if (dc || residual || (g.nj & 1) == 0)
             return -1;
@@ -1121,6 +1228,8 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
         return dispatch<0, 2>(a, env_cfg(small ? SweepCfg{2, 8, 2} : SweepCfg{4, 8, 1}), max_partials, s);
     if (dc && S == 2 && residual)
         return dispatch<2, 2>(a, env_cfg({4, 8, 1}), max_partials, s);
+    if (dc && S == 1 && residual)
+        return dispatch<1, 2>(a, env_cfg({4, 8, 1}), max_partials, s);
     if (dc && S == 4 && residual)
         return dispatch<4, 2>(a, env_cfg({2, 8, 2}), max_partials, s);
     if (dc)
@@ -1142,4 +1251,19 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
     if (S == 0 && residual)
         return dispatch<0, 1>(a, env_cfg({4, 8, 1}), max_partials, s);
     return -1;
+}
+
+int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
+            int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo, int acc_hi,
+            const Geom *gc, double *dc, int ic_lo, int ic_hi, const Geom *gce, const double *ec, int i_lo, int i_hi)
+{
+    return sweep_impl(g, vin, d, vout, r, partials, max_partials, h, S, c1, residual, s, acc_lo, acc_hi, gc, dc, ic_lo, ic_hi,
+                      gce, ec, i_lo, i_hi, false);
+}
+
+int k_sweep_tap(const Geom &g, const double *vin, const double *d, double *vout, double *partials, int max_partials,
+                double h, int c1, hipStream_t s, int acc_lo, int acc_hi)
+{
+    return sweep_impl(g, vin, d, vout, nullptr, partials, max_partials, h, 4, c1, false, s, acc_lo, acc_hi, nullptr, nullptr,
+                      -1, -1, nullptr, nullptr, -1, -1, true);
 }

@@ -672,6 +672,100 @@ def test_bottom_of_the_cycle_in_one_launch(monkeypatch, c, L, nu, dirty_r):
         assert np.any(H.d[0] != 0) and np.any(H.d[0].reshape(c, c, c)[0] != 0)  # the injected faces really are there
 
 
+@pytest.mark.parametrize("c,L,calls", [(9, 5, (5,)), (5, 6, (1, 2, 3)), (3, 7, (4, 1)), (17, 4, (6,)), (9, 6, (3,))])
+def test_carried_cycles_equal_the_plain_schedule_and_the_oracle(monkeypatch, c, L, calls):
+    """mg3d_vcycles on a V(2,2) problem of more than 65^3 points: every cycle but the last of a call ends with the launch
+    that also begins the next one (two post-smoothing passes, the norm tapped half-way, the next cycle's pre-smoothing
+    passes -- whose first, red, pass is the identity behind the previous cycle's last red pass), and that next cycle's
+    down-leg on the top level is ONE launch (one pass + residual + restriction).  Against the plain schedule
+    (MG3D_NO_CARRY=1): u and d of every level bit for bit, also across several calls (a call never ends in the carried
+    state); against the oracle: u of the finest level bit for bit, the history to summation-order accuracy."""
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MG3D_NO_CARRY", flag)
+        with M.Solver(c, L, 2) as s:
+            s.setup_test_problem()
+            norms = []
+            for k in calls:
+                norms += list(s.vcycles(k))
+            res.append((np.array(norms), [s.download(MG3D_U, l) for l in range(L)], [s.download(MG3D_D, l) for l in range(L - 1)]))
+    N = (c - 1) * (1 << (L - 1)) + 1
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=norm_rtol(N))
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert np.array_equal(a, b) and np.array_equal(np.signbit(a), np.signbit(b))
+    want_norms, want_u, _, _ = O.run_problem(c, L, 2, sum(calls))
+    assert np.array_equal(res[0][1][-1], want_u)
+    np.testing.assert_allclose(res[0][0], want_norms, rtol=norm_rtol(N))
+
+
+def test_single_cycle_calls_run_ahead_and_other_calls_put_the_result_back(monkeypatch):
+    """mg3d_vcycle (one cycle per call, the reference's solve loop) ends with the launch that also begins the next cycle.
+    Whatever comes between two cycles -- reading u, a new right-hand side, a smoothing sweep, a residual, a norm, a
+    changed sweep count, a raw device pointer -- must see and continue from the finished cycle's own u: the whole
+    interleaved sequence, step by step, bit for bit against the plain schedule (MG3D_NO_CARRY=1)."""
+    c, L = 9, 5
+    N = (c - 1) * (1 << (L - 1)) + 1
+    rng = np.random.default_rng(77)
+    d2 = rng.uniform(-1, 1, N ** 3)
+    logs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MG3D_NO_CARRY", flag)
+        log = []
+        with M.Solver(c, L, 2) as s:
+            top = L - 1
+            s.setup_test_problem()
+            s.timing_enable(1)
+            log.append(s.vcycle())
+            log.append(s.vcycle())
+            log.append(s.download(MG3D_U, top))          # the finished cycle's own u: made from the launch's input
+            log.append(s.vcycle())
+            s.upload(MG3D_D, top, d2)                    # a new right-hand side: the passes run ahead are void
+            log.append(s.vcycle())
+            log.append(s.vcycle())
+            s.smooth(top, 0, 1)
+            log.append(s.vcycle())
+            log.append(s.residual(top, True, True))
+            log.append(s.download(MG3D_R, top))
+            log.append(s.vcycle())
+            log.append(s.l2norm(MG3D_U, top))
+            log.append(s.vcycle())
+            log += list(s.vcycles(3))                    # a batch call behind single ones
+            log.append(s.vcycle())
+            log.append(s.vcycle(top - 1))                # a cycle from a lower level
+            log.append(s.vcycle())
+            s.fmg_initialize()
+            log.append(s.vcycle())
+            log.append(s.vcycle())
+            kt = {kn: n for (lvl, kn), (n, _) in s.kernel_times().items() if lvl == top}
+            log.append(s.download(MG3D_U, top))
+            log.append(s.download(MG3D_U, top - 1))
+            log.append(s.download(MG3D_D, top - 1))
+        logs.append(log)
+        if flag == "0":
+            assert kt.get("sweep4+norm", 0) >= 12 and kt.get("sweep1+restrict", 0) >= 6, kt
+        else:
+            assert "sweep4+norm" not in kt and "sweep1+restrict" not in kt, kt
+    assert len(logs[0]) == len(logs[1])
+    for i, (a, b) in enumerate(zip(logs[0], logs[1])):
+        if isinstance(a, np.ndarray):
+            assert np.array_equal(a, b), f"step {i}"
+        else:
+            np.testing.assert_allclose(a, b, rtol=norm_rtol(N), err_msg=f"step {i}")
+
+
+def test_carried_cycles_are_taken_and_counted(monkeypatch):
+    """The kernel timers name the launches: with carrying, K cycles make K-1 tap launches and K-1 one-pass restricting
+    launches on the top level, one ordinary start and one ordinary end."""
+    with M.Solver(9, 5, 2) as s:
+        s.setup_test_problem()
+        s.timing_enable(1)
+        s.vcycles(5)
+        kt = {kn: n for (lvl, kn), (n, _) in s.kernel_times().items() if lvl == 4}
+        s.timing_enable(0)
+    assert kt.get("sweep4+norm") == 4 and kt.get("sweep1+restrict") == 4, kt
+    assert kt.get("sweep4") == 1 and kt.get("sweep2+residual") == 1 and kt.get("sweep2") == 5 and kt.get("residual") == 1, kt
+
+
 @pytest.mark.parametrize("c,L", [(9, 4), (5, 5), (3, 6)])
 def test_one_sweep_down_leg_two_launches_equal_the_fused_shape(monkeypatch, c, L):
     """V(1,1): two colour passes + residual + restriction run as two launches by default (the one-launch shape spills
