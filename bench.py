@@ -456,6 +456,22 @@ def main():
 
     tm = solver.timing()
     kt = solver.kernel_times()
+    # the same K cycles with every cycle run on its own (MG3D_NO_CARRY=1: no launch shared between consecutive cycles,
+    # csrc/mg3d_ctx.hip "carried cycles"), no timers: reported beside `value`; both schedules give the same bits
+    plain = None
+    if world == 1 and not os.environ.get("MG3D_NO_CARRY"):
+        os.environ["MG3D_NO_CARRY"] = "1"
+        try:
+            solver.vcycles(2)
+            barrier(solver)
+            t1 = time.perf_counter()
+            solver.vcycles(args.steps)
+            barrier(solver)
+            el1 = time.perf_counter() - t1
+            plain = {"value": args.steps / el1, "ms_per_step": el1 / args.steps * 1e3,
+                     "what": "MG3D_NO_CARRY=1: four launches per cycle on the finest level, none shared between cycles"}
+        finally:
+            del os.environ["MG3D_NO_CARRY"]
     fin = L - 1
     n_f = N ** 3
 
@@ -590,6 +606,9 @@ def main():
             "smoother_hbm_gbs": smoother_gbs,
             "first_norm": float(norms[0]), "last_norm": float(norms[-1]), "initial_rhs_norm": init,
             "cycles_to_1e-8": to_tol,  # test_mg_3d.c stopping rule; the reference needs 16 at 513^3
+            # consecutive cycles of the timed call share a launch on the finest level (identical results)
+            "schedule": "carried cycles" if any(r["kernel"] == "sweep4+norm" for r in launches_tab) else "plain",
+            "plain_schedule": plain,
             "roofline": roof,
         }
         if args.breakdown:

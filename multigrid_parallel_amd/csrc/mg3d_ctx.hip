@@ -712,7 +712,7 @@ static int enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters
 static bool pro_fusable(const mg3d_ctx *ctx, int iters, int want_res, int level)
 {
     /* small levels: the two-rows-per-thread four-pass shape has the registers for the prolongation (k_sweep) */
-    const bool small = ctx->lv[level].g.N <= k_sweep_fuse_leg_max() && 2 * iters == 4 && want_res == 0;
+    const bool small = ctx->lv[level].g.N <= k_sweep_fuse_up_max() && 2 * iters == 4 && want_res == 0;
     /* On a 4-pass first launch it is opt-in (MG3D_PRO_FUSE=1): bit-identical, but measured SLOWER on MI355X at 513^3 --
      * the 4-pass sweep already uses 249 VGPRs, the prologue spills 44 dwords and the launch takes 1.48 ms against
      * 0.85 ms (sweep) + 0.56 ms (separate prolongation kernel).  The 2-pass first launch of a split stage takes it
@@ -844,8 +844,14 @@ bool mg3d_can_carry(const mg3d_ctx *ctx, int q)
     const char *e = getenv("MG3D_NO_CARRY"); /* read per call: tests toggle it */
     if (e && e[0] == '1')
         return false;
+    /* from 257^3 up: there the launch saved is bytes (257^3: +5 %, 513^3: +17 %, 1025^3: +16 % V-cycles/s); at 129^3 a
+     * launch is pipeline fill and the plain schedule's lighter launches are 1 % ahead.  MG3D_CARRY_MIN=<points per side>
+     * moves the threshold (tests run the 129^3 problems the oracle finishes in seconds); never on the levels that use
+     * the two-rows-per-thread shapes (no such shape for the two launches) */
+    const char *m = getenv("MG3D_CARRY_MIN");
+    const int n_min = m ? atoi(m) : 130;
     return ctx->fused && !ctx->keep_r && !ctx->have_es && ctx->iters == 2 && q == ctx->L - 1 && q >= 2 &&
-           ctx->lv[q].g.N > k_sweep_small_max() && (ctx->lv[q].g.nj & 1) != 0 && split_up_leg(2, 1) &&
+           ctx->lv[q].g.N >= n_min && ctx->lv[q].g.N > k_sweep_small_max() && (ctx->lv[q].g.nj & 1) != 0 && split_up_leg(2, 1) &&
            pro_fusable(ctx, 2, 1, q);
 }
 

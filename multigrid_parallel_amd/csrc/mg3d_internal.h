@@ -70,6 +70,7 @@ void k_fold(const double *partials, int np, double *out, hipStream_t s);
 void k_sweep_set_tune_default(int on); /* first-use chunk measurement on / off unless MG3D_SWEEP_TUNE says otherwise */
 int k_sweep_small_max(); /* MG3D_SMALL_MAX: largest level side that runs the two-rows-per-thread shapes (default 65) */
 int k_sweep_fuse_leg_max(); /* MG3D_FUSE_LEG_MAX: largest level side whose legs run as one launch each (default 65) */
+int k_sweep_fuse_up_max(); /* MG3D_FUSE_UP_MAX: largest level side whose up-leg is prolongation + four passes in ONE launch */
 bool k_sweep_fuse_rst2(); /* opt-in (MG3D_FUSE_RST2=1): two passes + residual + restriction as ONE launch */
 int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
             int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo = 0,

@@ -1161,6 +1161,13 @@ int k_sweep_fuse_leg_max() /* levels of at most this many points per side run a 
     return e ? atoi(e) : 0;
 }
 
+int k_sweep_fuse_up_max() /* levels of at most this many points per side take the prolongation into a four-pass up-leg launch */
+{
+    const char *e = getenv("MG3D_FUSE_UP_MAX");
+    const int v = e ? atoi(e) : 0;
+    return v > k_sweep_fuse_leg_max() ? v : k_sweep_fuse_leg_max();
+}
+
 bool k_sweep_fuse_rst2() /* MG3D_FUSE_RST2=1: keep the one-launch shape for two passes + residual + restriction */
 {
     const char *e = getenv("MG3D_FUSE_RST2"); /* read per stage, so that a test can compare both routes in one process */
@@ -1214,8 +1221,8 @@ static int sweep_impl(const Geom &g, const double *vin, const double *d, double 
         if (dc || residual || (g.nj & 1) == 0)
             return -1;
         if (S == 4) /* small levels: two rows per thread (no spills, 8 owned rows of 16); else the opt-in four-row shape */
-            return g.N <= k_sweep_fuse_leg_max() ? launch_sweep<4, 0, 2, 8, 2, true>(a, max_partials, s)
-                                                 : launch_sweep<4, 0, 4, 8, 1, true>(a, max_partials, s);
+            return g.N <= k_sweep_small_max() ? launch_sweep<4, 0, 2, 8, 2, true>(a, max_partials, s)
+                                              : launch_sweep<4, 0, 4, 8, 1, true>(a, max_partials, s);
         if (S == 2)
             return launch_sweep<2, 0, 4, 8, 1, true>(a, max_partials, s);
         return -1;

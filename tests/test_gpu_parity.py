@@ -681,6 +681,7 @@ def test_carried_cycles_equal_the_plain_schedule_and_the_oracle(monkeypatch, c, 
     (MG3D_NO_CARRY=1): u and d of every level bit for bit, also across several calls (a call never ends in the carried
     state); against the oracle: u of the finest level bit for bit, the history to summation-order accuracy."""
     res = []
+    monkeypatch.setenv("MG3D_CARRY_MIN", "66")  # (default: from 257^3 up -- the last case; the 129^3 ones are the cheap ones)
     for flag in ("0", "1"):
         monkeypatch.setenv("MG3D_NO_CARRY", flag)
         with M.Solver(c, L, 2) as s:
@@ -705,6 +706,7 @@ def test_single_cycle_calls_run_ahead_and_other_calls_put_the_result_back(monkey
     interleaved sequence, step by step, bit for bit against the plain schedule (MG3D_NO_CARRY=1)."""
     c, L = 9, 5
     N = (c - 1) * (1 << (L - 1)) + 1
+    monkeypatch.setenv("MG3D_CARRY_MIN", "66")
     rng = np.random.default_rng(77)
     d2 = rng.uniform(-1, 1, N ** 3)
     logs = []
@@ -756,12 +758,19 @@ def test_single_cycle_calls_run_ahead_and_other_calls_put_the_result_back(monkey
 def test_carried_cycles_are_taken_and_counted(monkeypatch):
     """The kernel timers name the launches: with carrying, K cycles make K-1 tap launches and K-1 one-pass restricting
     launches on the top level, one ordinary start and one ordinary end."""
+    monkeypatch.setenv("MG3D_CARRY_MIN", "66")
     with M.Solver(9, 5, 2) as s:
         s.setup_test_problem()
         s.timing_enable(1)
         s.vcycles(5)
         kt = {kn: n for (lvl, kn), (n, _) in s.kernel_times().items() if lvl == 4}
         s.timing_enable(0)
+    monkeypatch.delenv("MG3D_CARRY_MIN")
+    with M.Solver(9, 5, 2) as s:  # default threshold: a 129^3 problem runs the plain schedule
+        s.setup_test_problem()
+        s.timing_enable(1)
+        s.vcycles(3)
+        assert not any(kn == "sweep4+norm" for (lvl, kn) in s.kernel_times())
     assert kt.get("sweep4+norm") == 4 and kt.get("sweep1+restrict") == 4, kt
     assert kt.get("sweep4") == 1 and kt.get("sweep2+residual") == 1 and kt.get("sweep2") == 5 and kt.get("residual") == 1, kt
 

@@ -34,7 +34,7 @@ def load(d):
 
 
 A, B = load("pmc_fetch"), load("pmc_write")
-timer_of = {"sweep_kernel<4, 0,": "sweep4", "sweep_kernel<0, 2,": "residual", "sweep_kernel<2, 1,": "sweep2+residual",
+timer_of = {"sweep_kernel<4, 3,": "sweep4+norm", "sweep_kernel<1, 2,": "sweep1+restrict", "sweep_kernel<4, 0,": "sweep4", "sweep_kernel<0, 2,": "residual", "sweep_kernel<2, 1,": "sweep2+residual",
             "sweep_kernel<2, 0,": "sweep2", "prolong_cell_kernel": "prolong"}
 res, lines = {}, []
 for k in sorted(A, key=lambda k: -max(sum(v) / len(v) for (g, c), v in A[k].items() if c == "FETCH_SIZE")):
