@@ -104,7 +104,12 @@ int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm);
 /* One V-cycle from `level` down (vcycle, mg_3d.h:1242-1362); *norm receives the
  * post-smoothing residual norm of `level` (the value SolverLinSolve returns,
  * mg_3d.h:1415-1420).  mg3d_vcycles runs `count` cycles from the finest level
- * back to back with a single host synchronisation at the end. */
+ * back to back with a single host synchronisation at the end.
+ * Consecutive V(2,2) cycles from a finest level of at least 257^3 share a launch ("carried cycles"): the
+ * first red pre-smoothing pass of a cycle that follows another one is the identity, so a cycle's last two post-smoothing
+ * passes, its norm and the next cycle's pre-smoothing passes run as one launch.  mg3d_vcycles does so inside a call;
+ * mg3d_vcycle(finest level) ends ahead of itself, and every other entry point first restores the finished cycle's own u
+ * (observable results are those of separate cycles, bit for bit; MG3D_NO_CARRY=1 switches it off). */
 int mg3d_vcycle(mg3d_ctx *ctx, int level, double *norm);
 int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms);
 
