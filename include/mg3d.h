@@ -184,6 +184,7 @@ int mg3d_dist_destroy(mg3d_dist *d);
 int mg3d_dist_comm_info(const mg3d_dist *d, int *rccl_ranks, int *overlap, int *device);
 int mg3d_dist_first_level(const mg3d_dist *d); /* lowest distributed level */
 int mg3d_dist_halo(const mg3d_dist *d);        /* halo planes per side */
+int mg3d_dist_carried_cycles(const mg3d_dist *d); /* cycles since creation that ended ahead into the next one ("carried cycles") */
 int mg3d_dist_build_coarse(mg3d_dist *d, double h_coarse);
 int mg3d_dist_set_keep_residual(mg3d_dist *d, int keep); /* as mg3d_ctx_set_keep_residual */
 int mg3d_dist_upload(mg3d_dist *d, int field, int level, const double *host_full);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "mg3d_dist_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mg3d_dist_first_level": (C.c_int, [C.c_void_p]),
     "mg3d_dist_halo": (C.c_int, [C.c_void_p]),
+    "mg3d_dist_carried_cycles": (C.c_int, [C.c_void_p]),
     "mg3d_dist_set_keep_residual": (C.c_int, [C.c_void_p, C.c_int]),
     "mg3d_dist_build_coarse": (C.c_int, [C.c_void_p, C.c_double]),
     "mg3d_dist_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
@@ -393,6 +394,9 @@ class DistSolver:
         self.h = grid_length / (self.N - 1)
         self.first_level = self.L.mg3d_dist_first_level(self._h)
         self.halo = self.L.mg3d_dist_halo(self._h)
+
+    def carried_cycles(self):
+        return self.L.mg3d_dist_carried_cycles(self._h)
 
     def comm_info(self):
         """(ranks in the RCCL communicator, overlap on/off, HIP device)"""

@@ -846,7 +846,7 @@ bool mg3d_can_carry(const mg3d_ctx *ctx, int q)
         return false;
     /* from 257^3 up: there the launch saved is bytes (257^3: +5 %, 513^3: +17 %, 1025^3: +16 % V-cycles/s); at 129^3 a
      * launch is pipeline fill and the plain schedule's lighter launches are 1 % ahead.  MG3D_CARRY_MIN=<points per side>
-     * moves the threshold (tests run the 129^3 problems the oracle finishes in seconds); never on the levels that use
+     * moves the threshold (the tests run 129^3 problems); never on the levels that use
      * the two-rows-per-thread shapes (no such shape for the two launches) */
     const char *m = getenv("MG3D_CARRY_MIN");
     const int n_min = m ? atoi(m) : 130;

@@ -148,8 +148,15 @@ static int build_plan(Plan &pl, int c, int L, int P, int nu, int rank, int overl
     for (int l = G.ld; l < L; l++) { /* up */
         if (l - 1 >= G.ld)
             plan_halo(pl, G, MG3D_XK_HALO_U_UP, MG3D_U, l - 1, rank, 0, 0);
-        if (l == L - 1)
-            plan_halo(pl, G, MG3D_XK_HALO_U_NEXT, MG3D_U, l, rank, 1, cs);
+        if (l == L - 1) {
+            /* policy bit 1: the cycle is carried into the next one (csrc/mg3d_ctx.hip "carried cycles", V(2,2) only): its
+             * last launch has used up every halo plane and already holds three of the next cycle's pre-smoothing passes;
+             * the one launch left of that down-leg (one pass + residual + restriction) reads three planes either side */
+            if ((policy & 2) && nu == 2)
+                plan_halo(pl, G, MG3D_XK_HALO_U_NEXT, MG3D_U, l, rank, 0, cs, 3);
+            else
+                plan_halo(pl, G, MG3D_XK_HALO_U_NEXT, MG3D_U, l, rank, 1, cs);
+        }
     }
     plan_norm(pl, G, L - 1, rank);
     pl.begin.push_back((int)pl.e.size());
@@ -206,7 +213,11 @@ struct mg3d_dist {
     double *selftest; /* MG3D_FORCE_COMM=1 on one rank: H planes of the finest level, target of the self-addressed receives */
     /* the exchange plan of one cycle for every local rank (mg3d_dist_plan): the transports below execute it entry by
      * entry and hold no plane arithmetic of their own */
-    std::vector<Plan> plans;
+    std::vector<Plan> plans;       /* one cycle on its own */
+    std::vector<Plan> plans_carry; /* a cycle that ends ahead into the next one (policy bit 1) */
+    const std::vector<Plan> *cur;  /* the plan of the cycle being enqueued */
+    bool carried;                  /* u of the top level holds three pre-smoothing passes of the next cycle */
+    int n_carried;                 /* cycles that ended that way (mg3d_dist_carried_cycles) */
     int phase;  /* next phase of the cycle being enqueued */
     int policy; /* bit 0: coarse levels on rank 0 only (MG3D_COARSE_GATHER=1) */
     /* per-phase cost (mg3d_dist_timing_enable): event pairs, resolved at the next synchronisation */
@@ -513,6 +524,13 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
             return fail(rc, "mg3d_dist_create: no exchange plan for rank %d of %d", D->rs[ri].rank, nranks);
         }
     }
+    D->plans_carry.resize(D->rs.size());
+    for (size_t ri = 0; ri < D->rs.size(); ri++)
+        (void)build_plan(D->plans_carry[ri], coarse_pts, num_levels, nranks, smooth_iters, D->rs[ri].rank, D->overlap ? 1 : 0,
+                         D->policy | 2); /* same arguments as above: cannot fail where that did not */
+    D->cur = &D->plans;
+    D->carried = false;
+    D->n_carried = 0;
     *out = D;
     return MG3D_OK;
 }
@@ -565,6 +583,7 @@ extern "C" int mg3d_dist_comm_info(const mg3d_dist *D, int *rccl_ranks, int *ove
 
 extern "C" int mg3d_dist_first_level(const mg3d_dist *D) { return D ? D->ld : -1; }
 extern "C" int mg3d_dist_halo(const mg3d_dist *D) { return D ? D->H : -1; }
+extern "C" int mg3d_dist_carried_cycles(const mg3d_dist *D) { return D ? D->n_carried : -1; }
 
 extern "C" int mg3d_dist_set_keep_residual(mg3d_dist *D, int keep)
 {
@@ -659,7 +678,7 @@ extern "C" int mg3d_dist_sync(mg3d_dist *D)
 static int run_phase(mg3d_dist *D, int kind, int level, hipStream_t s)
 {
     const int ph = D->phase++;
-    for (auto &pl : D->plans)
+    for (auto &pl : *D->cur)
         if (ph >= (int)pl.kind.size() || pl.kind[(size_t)ph] != kind || pl.level[(size_t)ph] != level)
             return fail(MG3D_ERR_STATE, "slab schedule and exchange plan out of step at phase %d (schedule: kind %d level %d)",
                         ph, kind, level);
@@ -688,7 +707,7 @@ static int run_phase(mg3d_dist *D, int kind, int level, hipStream_t s)
     };
     auto sumsq = [&](size_t ri) -> double * { return D->rs[ri].coarse->sumsq; };
     ncclComm_t comm = (s == D->comm_stream && D->have_comm2) ? D->comm2 : D->comm;
-    return plan_run<double>(D->plans, ph, D->loopback, comm, ncclDouble, s, base, sumsq, D->rs[0].gather);
+    return plan_run<double>(*D->cur, ph, D->loopback, comm, ncclDouble, s, base, sumsq, D->rs[0].gather);
 }
 
 /* Start refreshing the u halos of level l behind everything queued on the compute stream so far, without
@@ -757,7 +776,9 @@ struct ProlongSource { /* per local rank: the coarse correction a split up-leg f
 static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const RestrictTarget *tgt,
                         bool zero_in = false /* u is identically zero: the first launch does not read it */,
                         bool refresh_u = false /* start the exchange of the u halos (planes 2..H) as soon as u is final */,
-                        const ProlongSource *pro = nullptr)
+                        const ProlongSource *pro = nullptr,
+                        bool tap = false /* carried cycle: the stage's last launch is four passes with the norm tapped after
+                                            the second -- the next cycle's first pre-smoothing passes ride on it */)
 {
     hipStream_t s = D->stream;
     const int c1 = post ? 0 : 1;
@@ -797,6 +818,16 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
                 w_lo = sl.own_lo - pad < 0 ? 0 : sl.own_lo - pad;
                 w_hi = sl.own_hi + pad > lv.g.ni ? lv.g.ni : sl.own_hi + pad;
             }
+            if (tap && last) {
+                /* output: the owned planes only -- the four passes use up the halo planes the first launch has left, and
+                 * the next launch (one pass + residual + restriction) gets three fresh ones by exchange first */
+                const int np = k_sweep_tap(lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt, cx->partials, MG3D_MAX_PARTIALS, lv.h, c1, s,
+                                           sl.own_lo, sl.own_hi, sl.own_lo, sl.own_hi);
+                if (np < 0)
+                    return fail(MG3D_ERR_STATE, "slab sweep: no kernel for four passes + norm tap on level %d", l);
+                k_fold(cx->partials, np, cx->sumsq, s);
+                continue;
+            }
             const int np = k_sweep(lv.g, (zero_in && first) ? nullptr : lv.f[MG3D_U], lv.f[MG3D_D], lv.alt,
                                    (res && want_res == 2 && !rst) ? lv.f[MG3D_R] : nullptr,
                                    (res && want_res == 1) ? cx->partials : nullptr, /* the pre-smoothing norm is dropped (:1294) */
@@ -827,11 +858,32 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
     return MG3D_OK;
 }
 
-static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
+/* carried cycles on slabs (csrc/mg3d_ctx.hip has the argument): same conditions as the single-domain path */
+static bool dist_can_carry(mg3d_dist *D)
+{
+    const char *e = getenv("MG3D_NO_CARRY");
+    if (e && e[0] == '1')
+        return false;
+    const char *m = getenv("MG3D_CARRY_MIN");
+    const int n_min = m ? atoi(m) : 130;
+    const Geom &g = SL(D, D->rs[0], D->L - 1).lv.g;
+    return D->nu == 2 && !D->rs[0].coarse->keep_r && g.N >= n_min && g.N > k_sweep_small_max() && (g.nj & 1) != 0 &&
+           dist_split_up_leg(D, 1, 1);
+}
+
+static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false)
 {
     hipStream_t s = D->stream;
     const int L = D->L, ld = D->ld;
     D->phase = 0;
+    const bool can = dist_can_carry(D), carry_in = D->carried;
+    if (carry_in && !can) {
+        D->carried = false;
+        return fail(MG3D_ERR_STATE, "mg3d_dist_vcycles: carried state met a cycle that cannot continue it");
+    }
+    carry_out = carry_out && can;
+    D->cur = carry_out ? &D->plans_carry : &D->plans;
+    D->carried = false;
     DistScope cycle_timer(D, 0, s);
     if (D->timing)
         D->t_cycles++;
@@ -866,6 +918,22 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
         const bool keep = D->rs[0].coarse->keep_r;
         std::vector<RestrictTarget> none(D->rs.size(), RestrictTarget{nullptr, nullptr, -1, -1});
         CHK(await_u(D, l));
+        if (l == L - 1 && carry_in) {
+            /* the one pre-smoothing pass that is left (black) + residual + restriction in one launch over the owned planes:
+             * it reads three planes either side, which the previous cycle's last exchange refreshed */
+            for (size_t ri = 0; ri < D->rs.size(); ri++) {
+                SlabLevel &sl = SL(D, D->rs[ri], l);
+                Level &lv = sl.lv;
+                const int np = k_sweep(lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt, nullptr, nullptr, MG3D_MAX_PARTIALS, lv.h, 1, 0,
+                                       true, s, sl.own_lo, sl.own_hi, tgt[ri].gc, tgt[ri].dc, tgt[ri].lo, tgt[ri].hi, nullptr,
+                                       nullptr, sl.own_lo, sl.own_hi);
+                if (np < 0)
+                    return fail(MG3D_ERR_STATE, "slab sweep: no kernel for one pass + residual + restriction on level %d", l);
+                double *t = lv.f[MG3D_U];
+                lv.f[MG3D_U] = lv.alt;
+                lv.alt = t;
+            }
+        } else
         /* :1282 + :1294 + :1310 (interior of the coarse rhs on the fly unless r is to be kept) */
         CHK(stage_smooth(D, l, 0, 2, keep ? none.data() : tgt.data(), l < L - 1));
         for (size_t ri = 0; ri < D->rs.size(); ri++) {
@@ -921,11 +989,15 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot)
          * 2*nu of them.  The next cycle's pre-smoother wants fresh halos on the finest u: that exchange starts
          * underneath the norm kernel, which reads the first halo plane on either side -- just produced
          * exactly by the post-smoother, so the exchange leaves that plane alone. */
-        CHK(stage_smooth(D, l, 1, want, nullptr, false, l == L - 1, fold ? pro.data() : nullptr));
+        CHK(stage_smooth(D, l, 1, want, nullptr, false, l == L - 1, fold ? pro.data() : nullptr, l == L - 1 && carry_out));
+        if (l == L - 1 && carry_out) {
+            D->carried = true;
+            D->n_carried++;
+        }
     }
     CHK(reduce_norm(D, slot));
-    if (D->phase != (int)D->plans[0].kind.size())
-        return fail(MG3D_ERR_STATE, "slab schedule ended after %d of the plan's %d phases", D->phase, (int)D->plans[0].kind.size());
+    if (D->phase != (int)(*D->cur)[0].kind.size())
+        return fail(MG3D_ERR_STATE, "slab schedule ended after %d of the plan's %d phases", D->phase, (int)(*D->cur)[0].kind.size());
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return fail(MG3D_ERR_HIP, "mg3d_dist_vcycles: kernel launch failed: %s", hipGetErrorString(e));
@@ -941,8 +1013,14 @@ extern "C" int mg3d_dist_vcycles(mg3d_dist *D, int count, double *norms)
         return fail(MG3D_ERR_ARG, "mg3d_dist_vcycles: bad arguments");
     for (int done = 0; done < count;) {
         const int nb = (count - done < D->norm_slots) ? count - done : D->norm_slots;
-        for (int c = 0; c < nb; c++)
-            CHK(dist_enqueue_vcycle(D, c));
+        for (int c = 0; c < nb; c++) {
+            /* every cycle but the last of a call ends ahead into the next one (a call never ends in the carried state) */
+            const int rc = dist_enqueue_vcycle(D, c, done + c + 1 < count);
+            if (rc != MG3D_OK) {
+                D->carried = false;
+                return rc;
+            }
+        }
         CHK(dist_finish(D));
         HIPCHK(hipMemcpyAsync(D->h_norms, D->d_norms, nb * sizeof(double), hipMemcpyDeviceToHost, D->stream));
         HIPCHK(hipStreamSynchronize(D->stream));

@@ -86,7 +86,7 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
  * (the launch that ends one V-cycle -- its last two post-smoothing passes and its norm -- and begins the next: mg3d_ctx.hip,
  * "carried cycles").  Returns the number of partials written or -1. */
 int k_sweep_tap(const Geom &g, const double *vin, const double *d, double *vout, double *partials, int max_partials,
-                double h, int c1, hipStream_t s, int acc_lo = 0, int acc_hi = -1);
+                double h, int c1, hipStream_t s, int acc_lo = 0, int acc_hi = -1, int i_lo = -1, int i_hi = -1);
 /* mg3d_tiny.hip: the level above the coarsest one in one workgroup (LDS-resident), when it fits (N <= 17) */
 bool k_tiny_fits(const Geom &g, const Geom &gc);
 /* zero guess, `iters` x (red, black), residual, restriction (interior + face injection from r's boundary) into dc */

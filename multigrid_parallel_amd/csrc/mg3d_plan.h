@@ -57,25 +57,27 @@ static inline int plan_open_phase(Plan &pl, int kind, int level)
     return (int)pl.kind.size() - 1;
 }
 
-/* Halo planes skip+1 .. H (counted from the slab's owned planes) of `field` on distributed level l from the neighbours'
- * owned planes; skip = 0 is the whole halo.  Halo plane t of the upper side is the upper neighbour's t-th owned plane, of
- * the lower side the lower neighbour's t-th from the top. */
-static inline void plan_halo(Plan &pl, const PlanGeom &G, int kind, int field, int level, int rank, int skip, int stream)
+/* Halo planes skip+1 .. skip+n (counted from the slab's owned planes; n < 0: up to H) of `field` on distributed level l
+ * from the neighbours' owned planes; skip = 0, n < 0 is the whole halo.  Halo plane t of the upper side is the upper
+ * neighbour's t-th owned plane, of the lower side the lower neighbour's t-th from the top. */
+static inline void plan_halo(Plan &pl, const PlanGeom &G, int kind, int field, int level, int rank, int skip, int stream,
+                             int n = -1)
 {
     const int phase = plan_open_phase(pl, kind, level);
-    const int n = G.H - skip;
+    if (n < 0 || skip + n > G.H)
+        n = G.H - skip;
     if (n <= 0)
         return;
     int lo, hi;
     long long pe;
     slab_local(G, level, rank, &lo, &hi, &pe);
     if (rank + 1 < G.P) {
-        pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_SEND, rank + 1, field, level, hi - G.H, n, pe, stream});
+        pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_SEND, rank + 1, field, level, hi - skip - n, n, pe, stream});
         pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_RECV, rank + 1, field, level, hi + skip, n, pe, stream});
     }
     if (rank > 0) {
         pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_SEND, rank - 1, field, level, lo + skip, n, pe, stream});
-        pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_RECV, rank - 1, field, level, lo - G.H, n, pe, stream});
+        pl.e.push_back(mg3d_xfer{phase, kind, MG3D_XOP_RECV, rank - 1, field, level, lo - skip - n, n, pe, stream});
     }
 }
 

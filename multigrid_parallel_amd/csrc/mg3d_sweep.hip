@@ -1269,8 +1269,8 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
 }
 
 int k_sweep_tap(const Geom &g, const double *vin, const double *d, double *vout, double *partials, int max_partials,
-                double h, int c1, hipStream_t s, int acc_lo, int acc_hi)
+                double h, int c1, hipStream_t s, int acc_lo, int acc_hi, int i_lo, int i_hi)
 {
     return sweep_impl(g, vin, d, vout, nullptr, partials, max_partials, h, 4, c1, false, s, acc_lo, acc_hi, nullptr, nullptr,
-                      -1, -1, nullptr, nullptr, -1, -1, true);
+                      -1, -1, nullptr, nullptr, i_lo, i_hi, true);
 }

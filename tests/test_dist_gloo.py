@@ -52,11 +52,14 @@ class PlanRunner:
     csrc/mg3d_dist.hip execute) over gloo: this test holds no plane arithmetic of its own for the transfers."""
 
     def __init__(self, c, L, P, nu, r, policy=0):
-        self.ph = PL.phases(c, L, P, nu, r, 0, policy)
+        self.plain = PL.phases(c, L, P, nu, r, 0, policy)
+        self.carried = PL.phases(c, L, P, nu, r, 0, policy | 2)  # a cycle that ends ahead into the next one
+        self.ph = self.plain
         self.r, self.cur = r, 0
 
-    def start_cycle(self):
+    def start_cycle(self, carry_out=False):
         self.cur = 0
+        self.ph = self.carried if carry_out else self.plain
 
     def run(self, kind, level, array_of, norm_part=None):
         """next phase of the cycle; array_of(field, level) -> the (planes, N, N) array the entries index"""
@@ -93,7 +96,7 @@ class PlanRunner:
         return gathered
 
 
-def worker(r, P, port, c, L, nu, cycles, out_path, policy=0):
+def worker(r, P, port, c, L, nu, cycles, out_path, policy=0, carry=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=r, world_size=P)
     lib = M.lib()
@@ -125,13 +128,19 @@ def worker(r, P, port, c, L, nu, cycles, out_path, policy=0):
             return getattr(lv[level], "ud"[field])
         return (Hc.u if field == 0 else Hc.d)[level].reshape(Ncr, Ncr, Ncr)
 
-    for _ in range(cycles):
-        plan.start_cycle()
+    carried = False  # u of the top level already holds the next cycle's first three pre-smoothing passes
+    for cyc in range(cycles):
+        # carried cycles (V(2,2); csrc/mg3d_dist.hip dist_enqueue_vcycle): every cycle but the last ends ahead
+        carry_in, carry_out = carried, carry and nu == 2 and cyc + 1 < cycles
+        plan.start_cycle(carry_out)
         for l in range(L - 1, ld - 1, -1):  # ---- down
             sl = lv[l]
             if l < L - 1:
                 sl.u[:] = 0.0
-            S.smooth(sl.u, sl.d, hs[l], nu, False, sl.ig0, sl.N)
+            if l == L - 1 and carry_in:
+                S.colour_pass(sl.u, sl.d, hs[l], 0, sl.ig0, sl.N)  # the one pre-smoothing pass that is left: black
+            else:
+                S.smooth(sl.u, sl.d, hs[l], nu, False, sl.ig0, sl.N)
             S.residual(sl.u, sl.d, hs[l], sl.r, sl.ig0, sl.N)
             if l - 1 >= ld:
                 sc = lv[l - 1]
@@ -168,9 +177,21 @@ def worker(r, P, port, c, L, nu, cycles, out_path, policy=0):
         # on the GPU the exchange below runs underneath the norm kernel, which reads the first halo plane:
         # that plane is left as the post-smoother produced it (exact), planes 2..H are refreshed
         top_before = top.u.copy()
-        plan.run(PL.HALO_U_NEXT, L - 1, array_of)
-        ss = S.residual(top_before, top.d, hs[L - 1], None, top.ig0, top.N, top.own_lo, top.own_hi)
-        assert ss == S.residual(top.u, top.d, hs[L - 1], None, top.ig0, top.N, top.own_lo, top.own_hi)
+        if carry_out:
+            # the launch that took the norm went on: the next cycle's pre-smoothing passes red (the identity behind the
+            # post-smoother's last red pass: checked here, skipped on the GPU), black, red -- every halo plane is used up,
+            # the plan's exchange brings three back, which the one pass + residual + restriction left of that down-leg read
+            ss = S.residual(top_before, top.d, hs[L - 1], None, top.ig0, top.N, top.own_lo, top.own_hi)
+            S.colour_pass(top.u, top.d, hs[L - 1], 1, top.ig0, top.N)
+            assert np.array_equal(top.u[top.own_lo:top.own_hi], top_before[top.own_lo:top.own_hi]), "red behind red: the identity"
+            S.colour_pass(top.u, top.d, hs[L - 1], 0, top.ig0, top.N)
+            S.colour_pass(top.u, top.d, hs[L - 1], 1, top.ig0, top.N)
+            plan.run(PL.HALO_U_NEXT, L - 1, array_of)
+        else:
+            plan.run(PL.HALO_U_NEXT, L - 1, array_of)
+            ss = S.residual(top_before, top.d, hs[L - 1], None, top.ig0, top.N, top.own_lo, top.own_hi)
+            assert ss == S.residual(top.u, top.d, hs[L - 1], None, top.ig0, top.N, top.own_lo, top.own_hi)
+        carried = carry_out
         parts = plan.run(PL.NORM, L - 1, array_of, norm_part=ss)
         assert plan.cur == len(plan.ph), "the cycle used every phase of the plan"
         norms.append(float(np.sqrt(sum(parts))))
@@ -191,13 +212,16 @@ def worker(r, P, port, c, L, nu, cycles, out_path, policy=0):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("c,L,nu,P,min_planes,policy", [(5, 5, 2, 2, 16, 0), (5, 5, 1, 2, 8, 0), (3, 6, 2, 3, 8, 0), (3, 6, 2, 3, 16, 0),
-                                                        (5, 5, 2, 2, 16, 1), (3, 6, 2, 3, 8, 1)])
-def test_slab_schedule_over_gloo(tmp_path, monkeypatch, c, L, nu, P, min_planes, policy):
+@pytest.mark.parametrize("c,L,nu,P,min_planes,policy,carry", [
+    (5, 5, 2, 2, 16, 0, False), (5, 5, 1, 2, 8, 0, False), (3, 6, 2, 3, 8, 0, False), (3, 6, 2, 3, 16, 0, False),
+    (5, 5, 2, 2, 16, 1, False), (3, 6, 2, 3, 8, 1, False),
+    # carried cycles: the schedule of V(2,2) cycles that end ahead into the next one, its plan variant (policy | 2)
+    (5, 5, 2, 2, 16, 0, True), (3, 6, 2, 3, 8, 0, True), (3, 6, 2, 3, 8, 1, True)])
+def test_slab_schedule_over_gloo(tmp_path, monkeypatch, c, L, nu, P, min_planes, policy, carry):
     monkeypatch.setenv("MG3D_SLAB_MIN_PLANES", str(min_planes))  # 8: thin slabs, three distributed levels
-    cycles = 3
+    cycles = 4 if carry else 3
     out = str(tmp_path / "res.npz")
-    mp.spawn(worker, args=(P, free_port(), c, L, nu, cycles, out, policy), nprocs=P, join=True)
+    mp.spawn(worker, args=(P, free_port(), c, L, nu, cycles, out, policy, carry), nprocs=P, join=True)
     got = np.load(out)
     O.lib().orc_set_threads(1)
     want_norms, want_u, _, _ = O.run_problem(c, L, nu, cycles)

@@ -26,7 +26,7 @@ def slab(c, L, P, H, level, r):
     return dict(ig0=glo - h_lo, ni=ghi - glo + h_lo + h_hi, own_lo=h_lo, own_hi=h_lo + ghi - glo)
 
 
-@pytest.mark.parametrize("policy", [0, 1])
+@pytest.mark.parametrize("policy", [0, 1, 2, 3])  # bit 0: coarse levels on rank 0; bit 1: the cycle is carried into the next
 @pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("P", [2, 3, 4, 8])
 @pytest.mark.parametrize("c,L,nu", CONFIGS)
@@ -194,3 +194,34 @@ def test_fp32_variant_every_send_has_its_receive(c, L, nu, P):
             if want_norm:
                 want.append((PL.NORM, q))
             assert seq == want
+
+
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
+@pytest.mark.parametrize("c,L,nu", CONFIGS)
+def test_carried_cycle_plan_differs_only_in_the_last_u_exchange(c, L, nu, P):
+    """policy bit 1 (a V(2,2) cycle that ends ahead into the next one, csrc/mg3d_ctx.hip "carried cycles"): the exchange
+    behind the cycle's last launch refreshes halo planes 1..3 (that launch has used up all of them; the next cycle's
+    one-pass + residual + restriction launch reads three either side) instead of 2..H.  Nothing else changes, and for any
+    other sweep count the bit changes nothing."""
+    lib = M.lib()
+    H = lib.mg3d_slab_halo(nu)
+    ld = lib.mg3d_slab_first_level(c, L, P, H)
+    if ld >= L:
+        pytest.skip("no level gives every rank enough planes")
+    for r in range(P):
+        plain, carried = PL.entries(c, L, P, nu, r, 0, 0), PL.entries(c, L, P, nu, r, 0, 2)
+        if nu != 2:
+            assert plain == carried
+            continue
+        assert len(plain) == len(carried)
+        sl = slab(c, L, P, H, L - 1, r)
+        for a, b in zip(plain, carried):
+            if a.kind != PL.HALO_U_NEXT:
+                assert a == b
+                continue
+            assert (a.phase, a.op, a.peer, a.field, a.level, a.plane_elems) == (b.phase, b.op, b.peer, b.field, b.level, b.plane_elems)
+            assert a.count == H - 1 and b.count == 3
+            if b.op == PL.SEND:  # the three owned planes next to the boundary the peer sits behind
+                assert b.offset == (sl["own_hi"] - 3 if b.peer == r + 1 else sl["own_lo"])
+            else:  # the three halo planes next to the owned ones
+                assert b.offset == (sl["own_hi"] if b.peer == r + 1 else sl["own_lo"] - 3)

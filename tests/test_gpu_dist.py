@@ -37,6 +37,31 @@ def test_slab_vcycles_match_single_domain(monkeypatch, c, L, nu, P, min_planes):
     np.testing.assert_allclose(norms, want_norms, rtol=1e-11, atol=0)
 
 
+@pytest.mark.parametrize("c,L,P,min_planes", [(9, 5, 2, 16), (9, 5, 8, 16), (9, 5, 4, 8), (5, 6, 4, 8), (3, 7, 3, 16), (9, 6, 4, 16),
+                                              (9, 6, 8, 8)])
+def test_slab_carried_cycles(monkeypatch, c, L, P, min_planes):
+    """Carried cycles on slabs (V(2,2), top level > 65^3; by default from 257^3 up -- the last two cases): every cycle but
+    the last of a call ends with the four-pass launch that taps the norm and begins the next cycle, the exchange behind it
+    refreshes three halo planes (plan variant `policy | 2`), the next down-leg is one launch.  Equal to the single domain
+    and to the slab path's plain schedule bit for bit, also over several calls."""
+    monkeypatch.setenv("MG3D_SLAB_MIN_PLANES", str(min_planes))
+    monkeypatch.setenv("MG3D_CARRY_MIN", "66")
+    want_norms, want_u = single(c, L, 2, 7)
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MG3D_NO_CARRY", flag)
+        with M.DistSolver(c, L, 2, nranks=P) as d:
+            d.setup_test_problem()
+            norms = list(d.vcycles(4)) + list(d.vcycles(1)) + list(d.vcycles(2))
+            assert d.carried_cycles() == (4 if flag == "0" else 0)  # 3 + 0 + 1
+            res.append((np.array(norms), d.download(MG3D_U, L - 1), [d.download(MG3D_U, l) for l in range(d.first_level, L - 1)]))
+    assert np.array_equal(res[0][1], want_u) and np.array_equal(res[1][1], want_u)
+    for a, b in zip(res[0][2], res[1][2]):
+        assert np.array_equal(a, b)
+    np.testing.assert_allclose(res[0][0], want_norms, rtol=1e-11, atol=0)
+    np.testing.assert_allclose(res[1][0], want_norms, rtol=1e-11, atol=0)
+
+
 @pytest.mark.parametrize("fuse", ["0", "1"])
 def test_slab_one_sweep_cycles_both_down_leg_routes(monkeypatch, fuse):
     """V(1,1) on slabs: the down-leg's two passes + residual + restriction as two launches (default) or as the one-launch
