@@ -881,11 +881,9 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, bool carry_out)
     const bool no_cyc = getenv("MG3D_NO_TINY_CYCLE") && getenv("MG3D_NO_TINY_CYCLE")[0] == '1';
     const bool tiny_cyc = tiny && !no_cyc && k_tiny_cycle_fits(ctx->lv[1].g, ctx->lv[0].g, ctx->lu, ctx->lu_in);
     const bool can_carry = mg3d_can_carry(ctx, q);
-    const bool carry_in = ctx->carried;
-    if (carry_in && !can_carry) { /* (cannot happen through the entry points: they drop the state first) */
+    if (ctx->carried && !can_carry) /* e.g. MG3D_NO_CARRY set between two calls: finish the carried cycle, go on plainly */
         drop_carry(ctx);
-        return fail(MG3D_ERR_STATE, "mg3d_vcycle: carried state met a cycle that cannot continue it");
-    }
+    const bool carry_in = ctx->carried;
     ctx->carried = false;
     for (int l = q; l >= 1; l--) {
         Level &lev = ctx->lv[l];

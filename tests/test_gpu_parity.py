@@ -733,6 +733,12 @@ def test_single_cycle_calls_run_ahead_and_other_calls_put_the_result_back(monkey
             log.append(s.vcycle())
             log += list(s.vcycles(3))                    # a batch call behind single ones
             log.append(s.vcycle())
+            if flag == "0":                              # the switch thrown while a cycle is carried: it is finished first
+                monkeypatch.setenv("MG3D_NO_CARRY", "1")
+            log.append(s.vcycle())
+            if flag == "0":
+                monkeypatch.setenv("MG3D_NO_CARRY", "0")
+            log.append(s.vcycle())
             log.append(s.vcycle(top - 1))                # a cycle from a lower level
             log.append(s.vcycle())
             s.fmg_initialize()
