@@ -17,10 +17,11 @@ t0 = time.time()
 for n in range(count):
     while True:
         c, L, nu = int(rng.integers(3, 14)), int(rng.integers(2, 7)), int(rng.integers(1, 4))
+        nu = int(os.environ.get("NU", nu))  # NU=2 NMIN=66 CYCLES=4 MG3D_CARRY_MIN=66: the carried-cycle schedule
         N = (c - 1) * (1 << (L - 1)) + 1
-        if 9 <= N <= 161 and c ** 3 <= 1400:
+        if max(9, int(os.environ.get("NMIN", "9"))) <= N <= 161 and c ** 3 <= 1400:
             break
-    cycles = 2
+    cycles = int(os.environ.get("CYCLES", "2"))
     want_norms, want_u, _, _ = O.run_problem(c, L, nu, cycles)
     with M.Solver(c, L, nu) as s:
         s.setup_test_problem()
