@@ -437,7 +437,7 @@ def main():
     # (csrc/mg3d_sweep.hip); one cycle, then the problem is set up afresh -- kept out of the warm-up so that --warmup 0
     # is valid and the residual history starts at the initial guess
     solver.setup_test_problem()
-    solver.vcycles(1)
+    solver.vcycles(3)  # three: the launches consecutive cycles share (carried cycles) meet the level here, not in the timed region
     solver.setup_test_problem()
     init = solver.get_initial_residual()
 
