@@ -239,7 +239,6 @@ void mg3d_drop_carry(mg3d_ctx *ctx)
     if (np < 0)
         (void)fail(MG3D_ERR_STATE, "carried cycle: the two passes that finish it could not be launched");
 }
-#define drop_carry mg3d_drop_carry
 
 void mg3d_ctx_touched(mg3d_ctx *ctx, int field, int level, bool raw_pointer)
 {
@@ -882,7 +881,7 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, bool carry_out)
     const bool tiny_cyc = tiny && !no_cyc && k_tiny_cycle_fits(ctx->lv[1].g, ctx->lv[0].g, ctx->lu, ctx->lu_in);
     const bool can_carry = mg3d_can_carry(ctx, q);
     if (ctx->carried && !can_carry) /* e.g. MG3D_NO_CARRY set between two calls: finish the carried cycle, go on plainly */
-        drop_carry(ctx);
+        mg3d_drop_carry(ctx);
     const bool carry_in = ctx->carried;
     ctx->carried = false;
     for (int l = q; l >= 1; l--) {
@@ -1057,14 +1056,14 @@ extern "C" int mg3d_vcycle(mg3d_ctx *ctx, int level, double *norm)
         return MG3D_OK;
     }
     if (level != ctx->L - 1)
-        drop_carry(ctx);
+        mg3d_drop_carry(ctx);
     /* One cycle per call is how the reference's solve loop runs (SolverLinSolve, mg_3d.h:1415-1420): the call ends with
      * the launch that also begins the NEXT cycle -- speculatively; whatever the caller does instead of another cycle
      * first puts the finished cycle's own u back (mg3d_drop_carry), and the norm returned is this cycle's either way.
      * Not once a raw pointer to u or d of the top level is out (mg3d_ctx_touched). */
     const int rc = mg3d_enqueue_vcycle(ctx, level, 0, !ctx->raw_top);
     if (rc != MG3D_OK) {
-        drop_carry(ctx);
+        mg3d_drop_carry(ctx);
         return rc;
     }
     return read_norm(ctx, 0, norm);
@@ -1085,10 +1084,10 @@ extern "C" int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms)
     }
     const int batch = ctx->sumsq_slots - 1;
     if (count == 0) /* (behind a single mg3d_vcycle call the first cycle continues from the carried state) */
-        drop_carry(ctx);
+        mg3d_drop_carry(ctx);
     struct Guard { /* an error return must not leave u of the top level a few passes into a cycle nobody asked for */
         mg3d_ctx *c;
-        ~Guard() { drop_carry(c); }
+        ~Guard() { mg3d_drop_carry(c); }
     } guard{ctx};
     for (int done = 0; done < count;) {
         const int nb = (count - done < batch) ? count - done : batch;
