@@ -579,18 +579,29 @@ def test_host_vcycle_started_below_the_finest_level():
         assert np.array_equal(G_.u[l], H.u[l]) and np.array_equal(G_.d[l], H.d[l]) and np.array_equal(G_.r[l], H.r[l])
 
 
-def test_full_size_513_bit_exact_against_oracle():
-    """BASELINE's headline size, two V(2,2) cycles: the whole 513^3 solution vector (1.08 GB) is bit-identical to the
-    oracle's (OpenMP over the host cores; the oracle's grid values do not depend on the thread count)."""
+def test_full_size_513_bit_exact_against_oracle(monkeypatch):
+    """BASELINE's headline size, three V(2,2) cycles (carried cycles, the default at this size: the second cycle both
+    continues the first and runs ahead into the third): the whole 513^3 solution vector (1.08 GB) is bit-identical to the
+    oracle's (OpenMP over the host cores; the oracle's grid values do not depend on the thread count) -- and to the
+    plain schedule's."""
     O.lib().orc_set_threads(min(16, os.cpu_count() or 1))
-    want_norms, want_u, _, _ = O.run_problem(9, 7, 2, 2)
+    want_norms, want_u, _, _ = O.run_problem(9, 7, 2, 3)
     with M.Solver(9, 7, 2) as s:
         s.setup_test_problem()
-        got = s.vcycles(2)
+        s.timing_enable(3)
+        got = s.vcycles(3)
+        assert {kn: n for (lvl, kn), (n, _) in s.kernel_times().items() if lvl == 6}.get("sweep4+norm") == 2
+        s.timing_enable(0)
         u = s.download(MG3D_U, 6)
     assert np.array_equal(u, want_u)
     np.testing.assert_allclose(got, want_norms, rtol=norm_rtol(513))
     O.lib().orc_set_threads(1)
+    monkeypatch.setenv("MG3D_NO_CARRY", "1")
+    with M.Solver(9, 7, 2) as s:
+        s.setup_test_problem()
+        plain = s.vcycles(3)
+        assert np.array_equal(s.download(MG3D_U, 6), want_u)
+    np.testing.assert_allclose(plain, want_norms, rtol=norm_rtol(513))
 
 
 def test_unknown_sweep_shape_falls_back_to_the_default(monkeypatch):
