@@ -135,14 +135,17 @@ def test_single_rank_builds_real_communicators(monkeypatch):
 def test_overlap_and_sequential_exchange_agree(monkeypatch):
     """MG3D_NO_OVERLAP=1 keeps every halo exchange on the compute stream; by default the large u exchanges run on
     a second stream underneath the coarser levels and the norm kernel."""
-    res = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("MG3D_NO_OVERLAP", flag)
-        with M.DistSolver(9, 5, 2, nranks=2) as d:
-            d.setup_test_problem()
-            res.append((d.vcycles(5), d.download(MG3D_U, 4)))
-    assert np.array_equal(res[0][0], res[1][0])
-    assert np.array_equal(res[0][1], res[1][1])
+    for carry_min in ("130", "66"):  # plain schedule / carried cycles (whose last u exchange is the three-plane one)
+        monkeypatch.setenv("MG3D_CARRY_MIN", carry_min)
+        res = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("MG3D_NO_OVERLAP", flag)
+            with M.DistSolver(9, 5, 2, nranks=2) as d:
+                d.setup_test_problem()
+                res.append((d.vcycles(5), d.download(MG3D_U, 4)))
+                assert d.carried_cycles() == (4 if carry_min == "66" else 0)
+        assert np.array_equal(res[0][0], res[1][0])
+        assert np.array_equal(res[0][1], res[1][1])
 
 
 @pytest.mark.parametrize("c,L,nu,P,min_planes", [(5, 5, 2, 4, 8), (9, 5, 2, 8, 16), (3, 6, 2, 3, 8), (9, 5, 1, 2, 16)])
