@@ -655,14 +655,14 @@ static int enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters
              * window leaves too few registers for a tile with a useful interior: measured 1.9 ms fused
              * against 0.85 + 0.76 ms split on a 513^3 level) */
             static const bool res4 = getenv("MG3D_FUSE_RES4") && getenv("MG3D_FUSE_RES4")[0] == '1'; /* experiment */
-            /* two passes + residual + restriction in one launch spills (156 bytes of scratch, 1.49 ms at 513^3 against
-             * 0.63 + 0.57 ms as two launches): with a restriction behind it the residual gets its own launch */
+            /* two passes + residual + restriction (the down-leg of V(1,1), the tail of V(3,3)'s): one launch from 130
+             * points per side up, two below (k_sweep_fuse_rst2) */
             /* small levels (<= MG3D_FUSE_LEG_MAX points per side): the whole down-leg -- four passes, residual,
              * restriction -- as one launch of the two-rows-per-thread shape: it wastes three quarters of its rows
              * and saves a launch where launches are paid in latency, not in bytes */
             const bool leg4 = S == 4 && coarse != nullptr && !need_norm && want_res != 0 && l.g.N <= k_sweep_fuse_leg_max();
             const bool res = last && want_res != 0 && (S != 4 || (res4 && coarse == nullptr) || leg4) &&
-                             !(S == 2 && coarse != nullptr && !k_sweep_fuse_rst2());
+                             !(S == 2 && coarse != nullptr && !k_sweep_fuse_rst2(l.g.N));
             const bool rst = res && coarse != nullptr;
             const bool with_pro = pro != nullptr && passes == 2 * iters; /* first launch only */
             int np;

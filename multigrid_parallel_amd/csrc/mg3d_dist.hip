@@ -788,9 +788,9 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
     while (passes > 0 || !done_res) {
         const int S = (sp && passes >= 2) ? 2 : passes >= 4 ? 4 : passes;
         const bool last = passes - S == 0;
-        /* two passes + residual + restriction in one launch spills (156 bytes of scratch, 1.49 ms at 513^3 against
-         * 0.63 + 0.57 ms as two launches): with a restriction behind it the residual gets its own launch */
-        const bool res = last && want_res != 0 && S != 4 && !(S == 2 && tgt != nullptr && !k_sweep_fuse_rst2());
+        /* two passes + residual + restriction: one launch from 130 points per side up, two below (k_sweep_fuse_rst2) */
+        const bool res = last && want_res != 0 && S != 4 &&
+                         !(S == 2 && tgt != nullptr && !k_sweep_fuse_rst2(SL(D, D->rs[0], l).lv.g.N));
         if (S == 0 && refresh_u) { /* u is final; the pure residual launch below reads owned +-1 only */
             CHK(start_u_exchange(D, MG3D_XK_HALO_U_NEXT, l));
             refresh_u = false;

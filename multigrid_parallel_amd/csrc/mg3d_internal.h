@@ -71,7 +71,7 @@ void k_sweep_set_tune_default(int on); /* first-use chunk measurement on / off u
 int k_sweep_small_max(); /* MG3D_SMALL_MAX: largest level side that runs the two-rows-per-thread shapes (default 65) */
 int k_sweep_fuse_leg_max(); /* MG3D_FUSE_LEG_MAX: largest level side whose legs run as one launch each (default 65) */
 int k_sweep_fuse_up_max(); /* MG3D_FUSE_UP_MAX: largest level side whose up-leg is prolongation + four passes in ONE launch */
-bool k_sweep_fuse_rst2(); /* opt-in (MG3D_FUSE_RST2=1): two passes + residual + restriction as ONE launch */
+bool k_sweep_fuse_rst2(int N); /* two passes + residual + restriction as ONE launch on a level of N points per side (default: from 130; MG3D_FUSE_RST2=0/1) */
 int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
             int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo = 0,
             int acc_hi = -1 /* local planes entering the norm; default all */,

@@ -1168,10 +1168,17 @@ int k_sweep_fuse_up_max() /* levels of at most this many points per side take th
     return v > k_sweep_fuse_leg_max() ? v : k_sweep_fuse_leg_max();
 }
 
-bool k_sweep_fuse_rst2() /* MG3D_FUSE_RST2=1: keep the one-launch shape for two passes + residual + restriction */
+bool k_sweep_fuse_rst2(int N) /* two passes + residual + restriction as ONE launch on a level of N points per side? */
 {
-    const char *e = getenv("MG3D_FUSE_RST2"); /* read per stage, so that a test can compare both routes in one process */
-    return e && e[0] == '1';
+    /* Since round 3 the shape has no scratch (the restriction overwrites its r pairs in place and parks them in LDS: 243
+     * VGPRs; round 2: 156 bytes of scratch, 1.49 ms at 513^3 against 0.63 + 0.57 ms as two launches) and one launch
+     * moves 3.4 GB instead of 5.5: V(1,1) at 513^3 2.70 -> 2.28 ms per cycle, 257^3 0.491 -> 0.460; at 129^3 and below
+     * (0.180 -> 0.195 ms) the split launches' two-row shapes stay ahead.  MG3D_FUSE_RST2=1 / 0: always / never (read per
+     * stage, so that a test can compare both routes in one process). */
+    const char *e = getenv("MG3D_FUSE_RST2");
+    if (e && (e[0] == '0' || e[0] == '1'))
+        return e[0] == '1';
+    return N >= 130;
 }
 
 static int sweep_impl(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,

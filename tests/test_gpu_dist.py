@@ -20,7 +20,7 @@ def single(c, L, nu, cycles):
 
 @pytest.mark.parametrize("min_planes", [8, 16])
 @pytest.mark.parametrize("c,L,nu,P", [(5, 5, 2, 2), (5, 5, 2, 4), (5, 5, 2, 8), (9, 5, 2, 8), (9, 5, 2, 2), (5, 5, 1, 4),
-                                      (5, 5, 3, 2), (3, 6, 2, 3), (9, 4, 2, 4), (9, 6, 2, 4)])
+                                      (5, 5, 3, 2), (3, 6, 2, 3), (9, 4, 2, 4), (9, 6, 2, 4), (9, 6, 1, 4), (9, 6, 3, 2)])
 def test_slab_vcycles_match_single_domain(monkeypatch, c, L, nu, P, min_planes):
     """min_planes 8: thin slabs, as many distributed levels as possible; 16: the default replication threshold."""
     if ((c - 1) << (L - 1)) // P < max(min_planes, 2 * nu + 2):

@@ -792,10 +792,11 @@ def test_carried_cycles_are_taken_and_counted(monkeypatch):
     assert kt.get("sweep4") == 1 and kt.get("sweep2+residual") == 1 and kt.get("sweep2") == 5 and kt.get("residual") == 1, kt
 
 
-@pytest.mark.parametrize("c,L", [(9, 4), (5, 5), (3, 6)])
+@pytest.mark.parametrize("c,L", [(9, 4), (5, 5), (3, 6), (9, 6)])
 def test_one_sweep_down_leg_two_launches_equal_the_fused_shape(monkeypatch, c, L):
-    """V(1,1): two colour passes + residual + restriction run as two launches by default (the one-launch shape spills
-    registers); MG3D_FUSE_RST2=1 keeps the one-launch shape.  Same bits, and both equal the oracle."""
+    """V(1,1): two colour passes + residual + restriction run as two launches (MG3D_FUSE_RST2=0; the default below 130
+    points per side) or as one (=1; the default from there up: no scratch since the restriction parks its r pairs in
+    LDS).  Same bits, and both equal the oracle."""
     res = []
     for flag in ("0", "1"):
         monkeypatch.setenv("MG3D_FUSE_RST2", flag)
