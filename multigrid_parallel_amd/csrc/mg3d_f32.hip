@@ -170,7 +170,10 @@ __device__ __forceinline__ double wave_sum32(double x)
  * in -- the prolongation costs neither a launch nor a pass over the fine level. */
 constexpr int CP_ROWS = 10, CP_COLS = 130;
 
-template <bool NORM, bool PRO>
+/* TAP: the residual norm of the INPUT field, formed where sweep 1 gathers the six neighbours of an input point anyway
+ * (a Jacobi sweep reads only old values: mg_3d.h:819-821 on operands the step already holds, no stage of its own) --
+ * the norm of the cycle before, when its last launch left it to this one ("carried cycles", e32_vcycle) */
+template <bool NORM, bool PRO, bool TAP = false>
 __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *__restrict__ vin,
                                                           const float *__restrict__ d, float *__restrict__ vout,
                                                           float hSq, float sixth, float omega, float invHsq,
@@ -329,7 +332,10 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
     /* The NORM / PRO variants need 73-103 VGPRs: one block per CU, nobody to hide a load behind.  They request the next
      * step's planes a step ahead (8 more registers, same occupancy); the plain pair runs two blocks per CU at 63 VGPRs
      * and must not grow. */
-    constexpr bool PREF = NORM || PRO;
+#ifndef MG3D_F32_TAP_PREF
+#define MG3D_F32_TAP_PREF 0 /* same-box A/B at 1025^3: 11.71 ms per cycle without, 12.26 with (plain schedule 12.54) */
+#endif
+    constexpr bool PREF = NORM || PRO || (TAP && MG3D_F32_TAP_PREF != 0); /* (TAP: 79 VGPRs; held to 64 it spills and the pair takes 30 % longer) */
     float4 raw_next = PREF ? load(vin, a0) : zero, d_next = PREF ? load(d, a0 - 1) : zero;
     for (int a = a0; a <= a1; a++) {
         float4 raw, d1;
@@ -373,6 +379,20 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
             const int q = a - 1;
             s_new = jacobi_pt4(in_m, in_p, ijm, ijp, left, in_c, right, d1, hSq, sixth, omega,
                                row_upd & (q >= pu_lo) & (q <= pu_hi), kin);
+            if constexpr (TAP) {
+                if (row_upd & (q >= i0) & (q < i1) & (q >= pu_lo) & (q <= pu_hi) & (q >= acc_lo) & (q < acc_hi)) { /* wave-uniform */
+                    const float hv[6] = {left, in_c.x, in_c.y, in_c.z, in_c.w, right};
+                    const float bl[4] = {in_m.x, in_m.y, in_m.z, in_m.w}, ab[4] = {in_p.x, in_p.y, in_p.z, in_p.w};
+                    const float jmv[4] = {ijm.x, ijm.y, ijm.z, ijm.w}, jpv[4] = {ijp.x, ijp.y, ijp.z, ijp.w};
+                    const float dv[4] = {d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const float ssum = sum6(bl[c], ab[c], jmv[c], jpv[c], hv[c], hv[c + 2]) - 6 * hv[c + 1];
+                        const float diff = dv[c] - invHsq * ssum;
+                        acc += kacc[c] ? (double)diff * (double)diff : 0.;
+                    }
+                }
+            }
         }
         s1b[r][lane] = s_new;
         /* sweep 2 of plane a-2 */
@@ -415,7 +435,7 @@ __global__ void __launch_bounds__(1024) jacobi32x2_kernel(Geom g, const float *_
         s_c = s_new;
         d2 = d1;
     }
-    if constexpr (NORM) {
+    if constexpr (NORM || TAP) {
         acc = wave_sum32(acc);
         if (lane == 0)
             red[r] = acc;
@@ -930,7 +950,7 @@ static int chunk_for(int planes, long long blocks_per_plane, long long want = 40
  * the last launch delivered it (paired sweep with the residual as third stage), false when a residual launch
  * still has to follow.  prolong_first: u += P(u of the next coarser level) before the first sweep (mg_3d.h:1331),
  * folded into the first paired launch when there is one. */
-bool e32_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot, bool prolong_first)
+bool e32_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot, bool prolong_first, int tap_slot)
 {
     Level32 &l = ctx->lv[level];
     const int gx = ((l.g.nk + 3) / 4 + 63) / 64, gy = (l.g.nj + 3) / 4;
@@ -951,22 +971,27 @@ bool e32_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot, bool prolo
         for (; it + 2 <= iters; it += 2) {
             const bool with_norm = norm_slot >= 0 && !no_fuse && it + 2 == iters;
             const bool with_pro = prolong_first && !no_fuse && it == 0;
+            /* tap_slot >= 0: ||d - A u|| of the field as it ENTERS this stage goes to sumsq[tap_slot] (the caller has
+             * checked e32_can_carry: the first launch is a plain pair) */
+            const bool with_tap = tap_slot >= 0 && it == 0 && !with_norm && !with_pro;
             const int py = (l.g.nj + (with_norm ? J2N_OUT_ROWS : J2_OUT_ROWS) - 1) / (with_norm ? J2N_OUT_ROWS : J2_OUT_ROWS);
             int ch = 128;
             if (const char *e = getenv("MG3D_F32_CH")) /* tuning knob: planes per i-chunk of the paired sweep */
                 ch = atoi(e) > 0 ? atoi(e) : ch;
             while (ch > 8 && (long long)px * py * ((l.g.ni + ch - 1) / ch) < 1024)
                 ch /= 2;
-            while (with_norm && (long long)px * py * ((l.g.ni + ch - 1) / ch) > MG3D_MAX_PARTIALS)
+            while ((with_norm || with_tap) && (long long)px * py * ((l.g.ni + ch - 1) / ch) > MG3D_MAX_PARTIALS)
                 ch *= 2;
             const dim3 grid(px, py, (l.g.ni + ch - 1) / ch), block(64, J2_ROWS, 1);
             const Geom gc = with_pro ? ctx->lv[level - 1].g : l.g;
             const float *ec = with_pro ? ctx->lv[level - 1].f[MG3D_U] : nullptr;
-            double *part = with_norm ? ctx->partials : nullptr;
-#define J2_LAUNCH(NORM, PRO)                                                                                       \
-    hipLaunchKernelGGL((jacobi32x2_kernel<NORM, PRO>), grid, block, 0, ctx->stream, l.g, l.f[MG3D_U], l.f[MG3D_D], \
+            double *part = (with_norm || with_tap) ? ctx->partials : nullptr;
+#define J2_LAUNCH(NORM, PRO, ...)                                                                                   \
+    hipLaunchKernelGGL((jacobi32x2_kernel<NORM, PRO, ##__VA_ARGS__>), grid, block, 0, ctx->stream, l.g, l.f[MG3D_U], l.f[MG3D_D], \
                        l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, l.invHsq, part, ch, gc, ec, l.own_lo, l.own_hi)
-            if (with_norm && with_pro)
+            if (with_tap)
+                J2_LAUNCH(false, false, true);
+            else if (with_norm && with_pro)
                 J2_LAUNCH(true, true);
             else if (with_norm)
                 J2_LAUNCH(true, false);
@@ -979,6 +1004,8 @@ bool e32_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot, bool prolo
                 k_fold(ctx->partials, (int)(grid.x * grid.y * grid.z), ctx->sumsq + norm_slot, ctx->stream);
                 normed = true;
             }
+            if (with_tap)
+                k_fold(ctx->partials, (int)(grid.x * grid.y * grid.z), ctx->sumsq + tap_slot, ctx->stream);
             swap();
         }
     }
@@ -1081,12 +1108,26 @@ static int launch_ok32(const char *who)
     return MG3D_OK;
 }
 
+/* Carried cycles, the Jacobi form.  A Jacobi sweep reads only old values, so the first pre-smoothing sweep of a cycle
+ * gathers, for every point, exactly the six neighbours the residual of the field it starts from is made of: the norm of
+ * cycle n (:1354) is a tap on cycle n+1's first launch (jacobi32x2_kernel<.,.,TAP>) instead of a third stage on cycle n's
+ * last one -- whose two-stage form (prolongation + two sweeps) keeps two more rows of its tile and one plane less in
+ * flight.  Nothing about u changes; only the norm arrives one launch later, inside the same mg3d32_vcycles call (the
+ * last cycle of a batch forms its own).  V(2,2) with the paired, fused launches only; MG3D_F32_NO_CARRY=1 switches it off. */
+bool e32_can_carry(const mg3d32_ctx *ctx)
+{
+    const char *e = getenv("MG3D_F32_NO_CARRY");
+    if (e && e[0] == '1')
+        return false;
+    return ctx->iters == 2 && !ctx->no_pairs && !ctx->no_fuse && ctx->L >= 2 && ctx->lv[ctx->L - 1].g.N >= 33;
+}
+
 /* the V-cycle of mg_3d.h:1242-1362 with the Jacobi smoother; the level's norm lands in sumsq[slot] */
-int e32_vcycle(mg3d32_ctx *ctx, int q, int slot)
+int e32_vcycle(mg3d32_ctx *ctx, int q, int slot, bool carry_out, int tap_slot)
 {
     if (q == 0)
         return e32_coarse_solve(ctx);
-    e32_jacobi(ctx, q, ctx->iters);                       /* :1282 */
+    e32_jacobi(ctx, q, ctx->iters, -1, false, tap_slot);  /* :1282 (+ the norm of the cycle before, :1354) */
     if (!ctx->no_fuse && ctx->lv[q].g.N >= 33) {
         e32_residual_restrict(ctx, q);                    /* :1294 + :1310, r not stored */
     } else {
@@ -1100,6 +1141,10 @@ int e32_vcycle(mg3d32_ctx *ctx, int q, int slot)
     const bool top = q == ctx->L - 1;
     if (ctx->iters == 0)
         e32_prolong(ctx, q);
+    if (top && carry_out) { /* the norm is the next cycle's first launch's to form */
+        e32_jacobi(ctx, q, ctx->iters, -1, true);
+        return MG3D_OK;
+    }
     if (!e32_jacobi(ctx, q, ctx->iters, top ? slot : -1, ctx->iters > 0) && top)
         e32_residual(ctx, q, false, slot);
     return MG3D_OK;
@@ -1181,8 +1226,9 @@ extern "C" int mg3d32_vcycles(mg3d32_ctx *ctx, int count, double *norms)
     const int slots = ctx->sumsq_slots - 1;
     for (int done = 0; done < count;) {
         const int nb = count - done < slots ? count - done : slots;
-        for (int c = 0; c < nb; c++)
-            CHK(e32_vcycle(ctx, ctx->L - 1, c));
+        const bool can = e32_can_carry(ctx);
+        for (int c = 0; c < nb; c++) /* every cycle of the batch but its last leaves its norm to the next one's first launch */
+            CHK(e32_vcycle(ctx, ctx->L - 1, c, can && c + 1 < nb, (can && c > 0) ? c - 1 : -1));
         CHK(launch_ok32("mg3d32_vcycles"));
         HIPCHK(hipMemcpyAsync(ctx->h_sumsq, ctx->sumsq, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -39,7 +39,7 @@ int mg3d32_create_slabs(int coarse_pts, int num_levels, int smooth_iters, double
                         int first_slab, const int *glo, const int *ghi, int halo, hipStream_t share, mg3d32_ctx **out);
 
 /* launchers on one context (asynchronous on its stream) */
-bool e32_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot = -1, bool prolong_first = false);
+bool e32_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot = -1, bool prolong_first = false, int tap_slot = -1);
 void e32_residual(mg3d32_ctx *ctx, int level, bool store, int slot);
 void e32_restrict(mg3d32_ctx *ctx, int level);
 /* residual + restriction of the coarse planes [c_lo, c_hi) (local indices of the coarser level; -1: those under
@@ -48,6 +48,9 @@ void e32_residual_restrict(mg3d32_ctx *ctx, int level, int c_lo = -1, int c_hi =
 void e32_prolong(mg3d32_ctx *ctx, int level);
 int e32_coarse_solve(mg3d32_ctx *ctx);
 void e32_fill_boundary(mg3d32_ctx *ctx, int field, int level);
-int e32_vcycle(mg3d32_ctx *ctx, int q, int slot);
+/* carry_out: the cycle's norm is left to the next cycle's first launch (which must pass tap_slot = this cycle's slot);
+ * only where e32_can_carry() */
+int e32_vcycle(mg3d32_ctx *ctx, int q, int slot, bool carry_out = false, int tap_slot = -1);
+bool e32_can_carry(const mg3d32_ctx *ctx);
 
 #endif

@@ -139,11 +139,13 @@ def test_large_level_shapes(c, L):
             assert np.array_equal(s.download(MG3D_U, top), want), f"{iters} sweeps at {N}^3"
 
 
-@pytest.mark.parametrize("knob", ["MG3D_F32_NO_PAIRS", "MG3D_F32_NO_FUSE"])
+@pytest.mark.parametrize("knob", ["MG3D_F32_NO_PAIRS", "MG3D_F32_NO_FUSE", "MG3D_F32_NO_CARRY"])
 def test_fused_and_separate_launches_agree(monkeypatch, knob):
     """MG3D_F32_NO_PAIRS=1 runs every sweep as its own launch, MG3D_F32_NO_FUSE=1 stores r and restricts it in a
     second launch and takes the norm in a launch of its own: same bits as the two-sweeps-per-launch, the
-    residual+restriction and the sweeps+norm kernels."""
+    residual+restriction and the sweeps+norm kernels.  MG3D_F32_NO_CARRY=1: every cycle forms its own norm as a third
+    stage of its last launch; by default all cycles of a call but the last leave it to a tap on the next cycle's first
+    sweep (a Jacobi sweep gathers the six neighbours of the field it starts from anyway)."""
     res = []
     for flag in ("0", "1"):
         monkeypatch.setenv(knob, flag)
