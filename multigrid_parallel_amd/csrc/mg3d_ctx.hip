@@ -845,12 +845,12 @@ bool mg3d_can_carry(const mg3d_ctx *ctx, int q)
         return false;
     /* from 257^3 up: there the launch saved is bytes (257^3: +5 %, 513^3: +17 %, 1025^3: +16 % V-cycles/s); at 129^3 a
      * launch is pipeline fill and the plain schedule's lighter launches are 1 % ahead.  MG3D_CARRY_MIN=<points per side>
-     * moves the threshold (the tests run 129^3 problems); never on the levels that use
-     * the two-rows-per-thread shapes (no such shape for the two launches) */
+     * moves the threshold (the tests run 129^3 problems); never at 65^3 and below (the two launches only exist in
+     * the four-rows-per-thread shapes) */
     const char *m = getenv("MG3D_CARRY_MIN");
     const int n_min = m ? atoi(m) : 130;
     return ctx->fused && !ctx->keep_r && !ctx->have_es && ctx->iters == 2 && q == ctx->L - 1 && q >= 2 &&
-           ctx->lv[q].g.N >= n_min && ctx->lv[q].g.N > k_sweep_small_max() && (ctx->lv[q].g.nj & 1) != 0 && split_up_leg(2, 1) &&
+           ctx->lv[q].g.N >= n_min && ctx->lv[q].g.N > 65 && (ctx->lv[q].g.nj & 1) != 0 && split_up_leg(2, 1) &&
            pro_fusable(ctx, 2, 1, q);
 }
 

@@ -867,7 +867,7 @@ static bool dist_can_carry(mg3d_dist *D)
     const char *m = getenv("MG3D_CARRY_MIN");
     const int n_min = m ? atoi(m) : 130;
     const Geom &g = SL(D, D->rs[0], D->L - 1).lv.g;
-    return D->nu == 2 && !D->rs[0].coarse->keep_r && g.N >= n_min && g.N > k_sweep_small_max() && (g.nj & 1) != 0 &&
+    return D->nu == 2 && !D->rs[0].coarse->keep_r && g.N >= n_min && g.N > 65 && (g.nj & 1) != 0 &&
            dist_split_up_leg(D, 1, 1);
 }
 

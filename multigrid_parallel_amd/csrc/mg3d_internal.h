@@ -68,7 +68,7 @@ void k_fold(const double *partials, int np, double *out, hipStream_t s);
  * receives it on the interior, partials (may be NULL) one sum of diff^2 per block.  Returns the number
  * of partials written (>= 0) or -1 when the (S, residual) shape has no instantiation. */
 void k_sweep_set_tune_default(int on); /* first-use chunk measurement on / off unless MG3D_SWEEP_TUNE says otherwise */
-int k_sweep_small_max(); /* MG3D_SMALL_MAX: largest level side that runs the two-rows-per-thread shapes (default 65) */
+int k_sweep_small_max(); /* MG3D_SMALL_MAX: largest level side that runs the two-rows-per-thread shapes (default 129) */
 int k_sweep_fuse_leg_max(); /* MG3D_FUSE_LEG_MAX: largest level side whose legs run as one launch each (default 65) */
 int k_sweep_fuse_up_max(); /* MG3D_FUSE_UP_MAX: largest level side whose up-leg is prolongation + four passes in ONE launch */
 bool k_sweep_fuse_rst2(int N); /* two passes + residual + restriction as ONE launch on a level of N points per side (default: from 130; MG3D_FUSE_RST2=0/1) */

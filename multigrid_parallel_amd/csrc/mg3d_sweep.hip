@@ -1148,8 +1148,12 @@ template <> int dispatch<4, 3>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
 
 int k_sweep_small_max() /* levels of at most this many points per side use the two-rows-per-thread shapes */
 {
+    /* 129 since the plane loop lost its guards (round 3): a 129^3 level is 12 tile columns x 21 chunks of 6 planes behind 8
+     * warm-up planes in the four-row shapes -- pipeline fill -- and the lighter two-row step wins: 129^3 problem 0.226 ->
+     * 0.219 ms per cycle, 257^3 0.558 -> 0.553, 513^3 +0.1-0.6 % (round 2 measured the two-row shapes 40 % slower at
+     * 257^3, where bytes count: still so) */
     const char *e = getenv("MG3D_SMALL_MAX"); /* 0: never */
-    return e ? atoi(e) : 65;
+    return e ? atoi(e) : 129;
 }
 
 int k_sweep_fuse_leg_max() /* levels of at most this many points per side run a whole leg of the cycle as ONE launch */
