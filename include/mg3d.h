@@ -140,6 +140,8 @@ enum {
     MG3D_K_SWEEP4_NORM,     /* carried cycles (mg3d_vcycles): a cycle's last 2 post-smoothing passes, its residual norm and
                                the next cycle's first pre-smoothing passes in one launch */
     MG3D_K_SWEEP1_RESTRICT, /* carried cycles: the last pre-smoothing pass + residual + restriction */
+    MG3D_K_LEG_DOWN,        /* one launch per leg: the pre-smoothing passes + residual + restriction */
+    MG3D_K_LEG_UP,          /* one launch per leg: prolongation + the post-smoothing passes (+ half of the norm) */
     MG3D_NUM_KERNELS
 };
 const char *mg3d_kernel_name(int kernel);

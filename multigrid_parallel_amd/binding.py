@@ -361,7 +361,9 @@ class Solver:
     def kernel_times(self):
         out = {}
         for l in range(self.num_levels):
-            for k in range(10):  # MG3D_NUM_KERNELS
+            for k in range(64):  # up to MG3D_NUM_KERNELS: the library names the ones it has
+                if self.L.mg3d_kernel_name(k) == b"?":
+                    break
                 calls, secs = C.c_int(0), C.c_double(0)
                 check(self.L.mg3d_kernel_time_get(self._h, l, k, C.byref(calls), C.byref(secs)))
                 if calls.value:

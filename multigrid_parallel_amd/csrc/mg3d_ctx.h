@@ -45,6 +45,12 @@ struct mg3d_ctx {
     /* carried cycles (mg3d_vcycles, see mg3d_enqueue_vcycle): u of the top level already holds the first three
      * pre-smoothing passes of the NEXT cycle; the finished cycle's own result is in the level's alt buffer */
     bool carried;
+    /* one launch per leg on the top level (mg3d_enqueue_vcycle, "two launches per level"): 0 nothing outstanding;
+     * 2 (inside mg3d_vcycles) the finished cycle's u is final, the second half of its norm rides on the next cycle's
+     * down-leg (legs_slot, legs_npa: where it goes, how many partial sums the up-leg left); 3 (behind mg3d_vcycle) the
+     * NEXT cycle's down-leg has already run, speculatively: u of the top level is three passes into it and the coarser
+     * level's next right-hand side sits in that level's alt buffer; the finished cycle's own u is in the top level's alt */
+    int legs_state, legs_slot, legs_npa;
     bool raw_top; /* a raw device pointer to u or d of the top level was handed out (mg3d_device_view) */
     bool fused; /* fused sweep kernel (default) or one launch per colour pass (MG3D_NO_FUSE=1) */
     int timing; /* 0 off, 1 every level, 2 finest level only, 3 finest level's kernel timers only, 4 + k: 3 on every (k+2)-th cycle */
@@ -67,8 +73,11 @@ int mg3d_fail(int code, const char *fmt, ...);
 /* enqueue one V-cycle from level q of a (single-domain) context; squared norm of level q to sumsq[slot] */
 /* carry_out: end the cycle with the launch that also starts the next one (only mg3d_vcycles asks, and never for the
  * last cycle of a call); ignored where mg3d_can_carry() says no */
-int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, bool carry_out = false);
+/* carry_out: 0 the cycle ends the ordinary way; 1 another cycle of the same call follows; 2 the call ends here and runs
+ * ahead speculatively (mg3d_vcycle) */
+int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out = 0);
 bool mg3d_can_carry(const mg3d_ctx *ctx, int q);
+bool mg3d_can_legs(const mg3d_ctx *ctx, int q);
 void mg3d_drop_carry(mg3d_ctx *ctx); /* carried state -> the finished cycle's own u; a no-op otherwise */
 
 #endif

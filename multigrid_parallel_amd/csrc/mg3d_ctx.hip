@@ -53,7 +53,7 @@ static const char *const kStageNames[MG3D_NUM_STAGES] = {"Smoother1",          "
 
 static const char *const kKernelNames[MG3D_NUM_KERNELS] = {"sweep4", "sweep2", "sweep2+residual", "residual",
                                                            "restrict", "prolong", "coarse_solve", "colour_pass",
-                                                           "sweep4+norm", "sweep1+restrict"};
+                                                           "sweep4+norm", "sweep1+restrict", "leg_down", "leg_up"};
 
 extern "C" const char *mg3d_kernel_name(int k) { return (k >= 0 && k < MG3D_NUM_KERNELS) ? kKernelNames[k] : "?"; }
 
@@ -213,6 +213,7 @@ static mg3d_ctx *ctx_new(int L, int iters)
     ctx->faces_always.assign(L, 0);
     ctx->fused = true;
     ctx->carried = false;
+    ctx->legs_state = ctx->legs_slot = ctx->legs_npa = 0;
     ctx->raw_top = false;
     ctx->keep_r = false;
     if (const char *e = getenv("MG3D_KEEP_R"))
@@ -230,6 +231,18 @@ static mg3d_ctx *ctx_new(int L, int iters)
  * mg3d_vcycle(s) continue from the carried state. */
 void mg3d_drop_carry(mg3d_ctx *ctx)
 {
+    if (ctx && ctx->legs_state != 0) {
+        /* one launch per leg: behind mg3d_vcycle the next cycle's down-leg has run ahead into the alt buffers; the finished
+         * cycle's own u is intact in the top level's alt, the coarser level's right-hand side was never touched -- swap
+         * back, no launch.  (State 2 only exists inside mg3d_vcycles: u is final, the norm's second half is abandoned.) */
+        if (ctx->legs_state == 3) {
+            Level &l = ctx->lv[ctx->L - 1];
+            double *t = l.f[MG3D_U];
+            l.f[MG3D_U] = l.alt;
+            l.alt = t;
+        }
+        ctx->legs_state = 0;
+    }
     if (!ctx || !ctx->carried)
         return;
     Level &l = ctx->lv[ctx->L - 1];
@@ -838,6 +851,28 @@ extern "C" int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm)
  * buffer; cycle n's own u (the tapped state) is never written -- mg3d_drop_carry makes it from that input when it is
  * wanted.  mg3d_vcycles never ends a call in the carried state (its last cycle ends the ordinary way); mg3d_vcycle does.  Only V(2,2) from the finest level of a context with
  * at least three levels, fused sweeps, r not kept; MG3D_NO_CARRY=1 switches it off (tests compare both). */
+/* One launch per leg ("two launches per level", round 4).  The alternating run of colour passes between two cycles
+ *      [prolongation] B R B R <norm of cycle n> (R = identity) B R B [residual, restriction]
+ * is cut at the norm instead: the up-leg is ONE launch (prolongation + four passes, k_sweep_leg_up) and the down-leg is ONE
+ * launch (three passes + residual + restriction, k_sweep_leg_down) -- 6 n w + 2 n_c w compulsory bytes per cycle on the top
+ * level instead of 9 n w + 2 n_c w.  No launch has a stage for the norm: the residual of the points the up-leg's last pass
+ * (red) has just updated falls out of that pass's neighbour sums, the residual of the black points out of the sums the
+ * next down-leg's first pass (black) forms before it updates them -- two runs of partial sums, folded into one norm.  The
+ * cycle's own u is the up-leg's output: nothing is speculative inside mg3d_vcycles.  Behind a single mg3d_vcycle call
+ * the next cycle's down-leg runs at once, into the alt buffers (u of the top level, d of the level below), so that the
+ * norm is complete when the call returns; whatever the caller does instead of another cycle swaps back
+ * (mg3d_drop_carry: no launch).  Same conditions as the carried cycles; MG3D_LEGS=0 / 1 switches it off / on. */
+bool mg3d_can_legs(const mg3d_ctx *ctx, int q)
+{
+    const char *e = getenv("MG3D_LEGS"); /* read per call: tests toggle it */
+    const bool on = e ? e[0] == '1' : false;
+    if (!on)
+        return false;
+    const char *m = getenv("MG3D_LEGS_MIN");
+    const int n_min = m ? atoi(m) : 130;
+    return mg3d_can_carry(ctx, q) && ctx->lv[q].g.N >= n_min;
+}
+
 bool mg3d_can_carry(const mg3d_ctx *ctx, int q)
 {
     const char *e = getenv("MG3D_NO_CARRY"); /* read per call: tests toggle it */
@@ -854,7 +889,7 @@ bool mg3d_can_carry(const mg3d_ctx *ctx, int q)
            pro_fusable(ctx, 2, 1, q);
 }
 
-int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, bool carry_out)
+int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out)
 {
     if (!ctx->have_lu)
         return fail(MG3D_ERR_STATE, "mg3d_vcycle: no coarse LU set (mg3d_ctx_build_coarse / mg3d_ctx_set_lu)");
@@ -879,13 +914,52 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, bool carry_out)
      * factor exists (mg3d_tiny.hip, tiny_cycle_kernel); MG3D_NO_TINY_CYCLE=1 keeps the three launches (tests compare) */
     const bool no_cyc = getenv("MG3D_NO_TINY_CYCLE") && getenv("MG3D_NO_TINY_CYCLE")[0] == '1';
     const bool tiny_cyc = tiny && !no_cyc && k_tiny_cycle_fits(ctx->lv[1].g, ctx->lv[0].g, ctx->lu, ctx->lu_in);
-    const bool can_carry = mg3d_can_carry(ctx, q);
-    if (ctx->carried && !can_carry) /* e.g. MG3D_NO_CARRY set between two calls: finish the carried cycle, go on plainly */
+    const bool can_legs = mg3d_can_legs(ctx, q);
+    const bool can_carry = !can_legs && mg3d_can_carry(ctx, q);
+    if ((ctx->carried && !can_carry) || (ctx->legs_state != 0 && !can_legs)) /* e.g. MG3D_NO_CARRY set between two calls: finish the carried cycle, go on plainly */
         mg3d_drop_carry(ctx);
     const bool carry_in = ctx->carried;
     ctx->carried = false;
+    const int legs_in = ctx->legs_state;
+    ctx->legs_state = 0;
+    double *const part_a = ctx->partials, *const part_b = ctx->partials + MG3D_MAX_PARTIALS / 2;
     for (int l = q; l >= 1; l--) {
         Level &lev = ctx->lv[l];
+        if (l == q && can_legs) {
+            Level &lc = ctx->lv[l - 1];
+            {
+                StageScope t(ctx, l, MG3D_ST_SMOOTH1);
+                if (legs_in == 3) {
+                    /* this cycle's down-leg ran behind the previous mg3d_vcycle call: its u is the top level's u already,
+                     * its restricted residual sits in the coarser level's alt buffer */
+                    double *t2 = lc.f[MG3D_D];
+                    lc.f[MG3D_D] = lc.alt;
+                    lc.alt = t2;
+                    ctx->faces_dirty[l] = 1; /* the two buffers take turns as d: inject the faces into this one */
+                } else {
+                    StageScope kt(ctx, l, MG3D_K_LEG_DOWN, true);
+                    /* behind another cycle: black, red, black (the first red pass is the identity) and the black half of
+                     * that cycle's norm; else the four passes of :1282.  + residual + restriction (:1294 + :1310) */
+                    const int np = k_sweep_leg_down(lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, lc.g, lc.f[MG3D_D], lev.h,
+                                                    legs_in == 2 ? 3 : 4, legs_in == 2 ? part_b : nullptr, MG3D_MAX_PARTIALS / 2, s);
+                    if (np < 0)
+                        return fail(MG3D_ERR_STATE, "one launch per leg: no kernel for the down-leg");
+                    double *t2 = lev.f[MG3D_U];
+                    lev.f[MG3D_U] = lev.alt;
+                    lev.alt = t2;
+                    if (legs_in == 2)
+                        k_fold2(part_a, ctx->legs_npa, part_b, np, ctx->sumsq + ctx->legs_slot, s);
+                }
+            }
+            { StageScope t(ctx, l, MG3D_ST_RESIDUAL1); }
+            StageScope t(ctx, l, MG3D_ST_RESTRICT);
+            if (ctx->faces_dirty[l] || ctx->faces_always[l]) {
+                StageScope kt(ctx, l, MG3D_K_RESTRICT, true);
+                k_restrict(lev.g, lev.f[MG3D_R], lc.g, lc.f[MG3D_D], s, -1, -1, true);
+                ctx->faces_dirty[l] = 0;
+            }
+            continue;
+        }
         if (l == q && carry_in) {
             { /* the one pre-smoothing pass that is left (black) + residual + restriction (:1282 + :1294 + :1310) */
                 StageScope t(ctx, l, MG3D_ST_SMOOTH1);
@@ -993,6 +1067,49 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, bool carry_out)
             { StageScope t(ctx, l, MG3D_ST_RESIDUAL2); }
             continue;
         }
+        if (l == q && can_legs) {
+            Level &lc = ctx->lv[l - 1];
+            { StageScope t(ctx, l, MG3D_ST_PROLONG); } /* :1331, folded into the launch below */
+            {
+                StageScope t(ctx, l, MG3D_ST_SMOOTH2);
+                int npa;
+                {
+                    StageScope kt(ctx, l, MG3D_K_LEG_UP, true);
+                    /* prolongation + black, red, black, red (:1331 + :1341); with another cycle behind it, the red half of
+                     * the norm (:1354) from the last pass's sums */
+                    npa = k_sweep_leg_up(lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, lc.g, lc.f[MG3D_U], lev.h,
+                                         carry_out ? part_a : nullptr, MG3D_MAX_PARTIALS / 2, s);
+                }
+                if (npa < 0)
+                    return fail(MG3D_ERR_STATE, "one launch per leg: no kernel for the up-leg");
+                double *t2 = lev.f[MG3D_U];
+                lev.f[MG3D_U] = lev.alt;
+                lev.alt = t2;
+                if (carry_out == 1) { /* the next cycle of this mg3d_vcycles call completes the norm */
+                    ctx->legs_state = 2;
+                    ctx->legs_slot = slot;
+                    ctx->legs_npa = npa;
+                } else if (carry_out == 2) {
+                    /* mg3d_vcycle: the next cycle's down-leg now, into the alt buffers (see mg3d_can_legs) */
+                    StageScope kt(ctx, l, MG3D_K_LEG_DOWN, true);
+                    const int npb = k_sweep_leg_down(lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, lc.g, lc.alt, lev.h, 3, part_b,
+                                                     MG3D_MAX_PARTIALS / 2, s);
+                    if (npb < 0)
+                        return fail(MG3D_ERR_STATE, "one launch per leg: no kernel for the down-leg");
+                    double *t3 = lev.f[MG3D_U];
+                    lev.f[MG3D_U] = lev.alt;
+                    lev.alt = t3;
+                    k_fold2(part_a, npa, part_b, npb, ctx->sumsq + slot, s);
+                    ctx->legs_state = 3;
+                }
+            }
+            {
+                StageScope t(ctx, l, MG3D_ST_RESIDUAL2);
+                if (!carry_out)
+                    CHK(enqueue_residual(ctx, l, 0, slot)); /* :1354, the last cycle of a call: a launch of its own */
+            }
+            continue;
+        }
         if (l == q && carry_out && can_carry) {
             { StageScope t(ctx, l, MG3D_ST_PROLONG); } /* :1331, folded into the launch below */
             {
@@ -1061,7 +1178,7 @@ extern "C" int mg3d_vcycle(mg3d_ctx *ctx, int level, double *norm)
      * the launch that also begins the NEXT cycle -- speculatively; whatever the caller does instead of another cycle
      * first puts the finished cycle's own u back (mg3d_drop_carry), and the norm returned is this cycle's either way.
      * Not once a raw pointer to u or d of the top level is out (mg3d_ctx_touched). */
-    const int rc = mg3d_enqueue_vcycle(ctx, level, 0, !ctx->raw_top);
+    const int rc = mg3d_enqueue_vcycle(ctx, level, 0, ctx->raw_top ? 0 : 2);
     if (rc != MG3D_OK) {
         mg3d_drop_carry(ctx);
         return rc;
@@ -1092,7 +1209,8 @@ extern "C" int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms)
     for (int done = 0; done < count;) {
         const int nb = (count - done < batch) ? count - done : batch;
         for (int c = 0; c < nb; c++)
-            CHK(mg3d_enqueue_vcycle(ctx, q, c, done + c + 1 < count)); /* every cycle but the last carries into the next */
+            /* every cycle but the last carries into the next; one launch per leg: not across a batch's norm read-back */
+            CHK(mg3d_enqueue_vcycle(ctx, q, c, (done + c + 1 < count && (c + 1 < nb || !mg3d_can_legs(ctx, q))) ? 1 : 0));
         HIPCHK(hipMemcpyAsync(ctx->h_sumsq, ctx->sumsq, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         resolve_timers(ctx);

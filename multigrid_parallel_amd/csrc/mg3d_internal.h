@@ -63,6 +63,8 @@ void k_prolong(const Geom &gc, const double *ec, const Geom &gf, double *ef, hip
 void k_fill_boundary(const Geom &g, double *v, double h, hipStream_t s);
 /* folds np per-block partial sums, in a fixed order, into *out */
 void k_fold(const double *partials, int np, double *out, hipStream_t s);
+/* the same over two runs of partial sums (a norm whose halves two launches formed): *out = fold(pa) + fold(pb) */
+void k_fold2(const double *pa, int na, const double *pb, int nb, double *out, hipStream_t s);
 /* fused sweep (mg3d_sweep.hip): S colour passes starting with colour c1 (1 red, 0 black) from vin into
  * vout (vout != vin; ignored when S == 0), then optionally the residual of the result: r (may be NULL)
  * receives it on the interior, partials (may be NULL) one sum of diff^2 per block.  Returns the number
@@ -87,6 +89,17 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
  * "carried cycles").  Returns the number of partials written or -1. */
 int k_sweep_tap(const Geom &g, const double *vin, const double *d, double *vout, double *partials, int max_partials,
                 double h, int c1, hipStream_t s, int acc_lo = 0, int acc_hi = -1, int i_lo = -1, int i_hi = -1);
+/* One launch per leg of a V(2,2) cycle on a level (mg3d_sweep.hip, "one launch per leg").  down: S = 4 colour passes red
+ * first, or S = 3 black first (behind another cycle), + residual + full-weighting restriction into the interior of dc;
+ * partials (S = 3 only): sum of diff^2 of the INCOMING state over the colour the first pass updates.  up: the input is
+ * vin + P(ec), four passes black first; partials: sum of diff^2 of the RESULT over the colour the last pass updated.
+ * Return value as k_sweep. */
+int k_sweep_leg_down(const Geom &g, const double *vin, const double *d, double *vout, const Geom &gc, double *dc, double h, int S,
+                     double *partials, int max_partials, hipStream_t s, int acc_lo = 0, int acc_hi = -1, int ic_lo = -1,
+                     int ic_hi = -1, int i_lo = -1, int i_hi = -1);
+int k_sweep_leg_up(const Geom &g, const double *vin, const double *d, double *vout, const Geom &gce, const double *ec, double h,
+                   double *partials, int max_partials, hipStream_t s, int acc_lo = 0, int acc_hi = -1, int i_lo = -1,
+                   int i_hi = -1);
 /* mg3d_tiny.hip: the level above the coarsest one in one workgroup (LDS-resident), when it fits (N <= 17) */
 bool k_tiny_fits(const Geom &g, const Geom &gc);
 /* zero guess, `iters` x (red, black), residual, restriction (interior + face injection from r's boundary) into dc */

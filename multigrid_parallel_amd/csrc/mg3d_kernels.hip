@@ -159,6 +159,28 @@ __global__ void __launch_bounds__(256) residual_kernel(Geom g, const double *__r
         partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = tot;
 }
 
+__global__ void __launch_bounds__(256) fold2_partials_kernel(const double *__restrict__ pa, int na,
+                                                             const double *__restrict__ pb, int nb, double *__restrict__ out)
+{
+    __shared__ double lds4[4];
+    double acc = 0.;
+    for (int t = threadIdx.x; t < na; t += 256)
+        acc += pa[t];
+    const double ta = block_sum_256(acc, lds4);
+    __syncthreads();
+    acc = 0.;
+    for (int t = threadIdx.x; t < nb; t += 256)
+        acc += pb[t];
+    const double tb = block_sum_256(acc, lds4);
+    if (threadIdx.x == 0)
+        *out = ta + tb;
+}
+
+void k_fold2(const double *pa, int na, const double *pb, int nb, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(fold2_partials_kernel, dim3(1), dim3(256), 0, s, pa, na, pb, nb, out);
+}
+
 void k_fold(const double *partials, int np, double *out, hipStream_t s)
 {
     hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, partials, np, out);

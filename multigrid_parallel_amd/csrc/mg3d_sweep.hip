@@ -55,776 +55,7 @@
 #include <mutex>
 #include <vector>
 
-#define WAVE 64
-
-struct SweepArgs {
-    Geom g;
-    const double *vin;
-    const double *d;
-    double *vout;     /* may equal nullptr when S == 0 */
-    double *r;        /* residual store (interior only) or nullptr */
-    double *partials; /* one partial sum of diff^2 per block, or nullptr */
-    double hSq, sixth, invHsq;
-    int c1;         /* colour of the first pass: 1 red, 0 black */
-    int ntj, ntk;   /* tiles in j, k */
-    int vk, hk;     /* k-tiling: tile tk covers columns [vk*tk, vk*tk + 128) and owns those at least hk from its
-                       edges (a tile edge on the global boundary needs no halo); vk = 128 - 2*hk */
-    int snap;       /* segment cuts closer than this to a tile column's end move onto it */
-    int CI;         /* > 0: lock-step mode, planes per i-chunk; 0: equal shares of the linearised work */
-    int i_lo, i_hi;     /* local output planes this launch produces */
-    int acc_lo, acc_hi; /* local planes whose diff^2 enter the norm (owned planes of a slab) */
-    /* fused prolongation (PRO): the level's input is vin + P(ec) (mg_3d.h:1000-1145); gce = geometry of ec */
-    const double *ec;
-    Geom gce;
-    /* fused restriction (RES == 2): coarse geometry, coarse right-hand side, local coarse planes to write */
-    Geom gc;
-    double *dc;
-    int ic_lo, ic_hi;
-    int xcd_remap;  /* 1: blocks of one XCD group (blockIdx % 8) take consecutive shares of the work */
-    int rev;        /* 1: the i-chunks are handed out last to first (the launch before it ended on the last planes: what of
-                       them is still in the Infinity Cache is read first).  Speed only. */
-};
-
-/* RES: 0 = smoothing only, 1 = + residual (r store and/or norm), 2 = + residual AND full-weighting
- * restriction of it into the coarse right-hand side (mg_3d.h:961-995) -- r never travels to HBM;
- * 3 = the residual NORM of the state half-way through the passes (after pass S/2), see "tap" in the kernel.
- * The 27-point restriction stencil reaches one fine point beyond the coarse point's centre, so its halo
- * and warm-up are one deeper. */
-template <int S, int RES> struct SweepShape {
-    /* With S > 0 the residual of the colour updated last falls out of stage S itself (same neighbour
-     * sum), the other colour needs one more gather: ST = S + 1.  A pure residual (S == 0) needs both. */
-    static constexpr bool TAIL = RES == 1 || RES == 2; /* a residual BEHIND the passes (the tap costs no stage) */
-    static constexpr int ST = S + (TAIL ? (S > 0 ? 1 : 2) : 0); /* pipeline stages */
-    /* halo rows; even where the restriction rides along: its coarse rows are centred on a thread's EVEN rows, so a tile's
-     * first row must be an even row of the level (one pass + residual + restriction: 4, not 3) */
-    static constexpr int HJ = RES == 2 ? ((S + 2 + 1) & ~1) : S + (TAIL ? 1 : 0);
-    static constexpr int HK = (HJ + 1) & ~1;     /* halo columns, even so pairs stay aligned */
-    static constexpr int HI = S + (TAIL ? 1 : 0) + (RES == 2 ? 1 : 0); /* warm-up planes */
-};
-
-/* One-lane shifts across the whole wave as DPP moves (v_mov_b32_dpp wave_shr:1 / wave_shl:1, two per
- * double): VALU-rate, no LDS crossbar.  Lane 0 / lane 63 have no source and read 0 (tile halo, never used). */
-template <int CTRL> __device__ __forceinline__ double dpp_move(double x)
-{
-    const long long b = __double_as_longlong(x);
-    const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-    /* bound_ctrl: the lane without a source (0 or 63, a tile-halo lane) reads 0; no copy of the old value */
-    const int rlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-    const int rhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-    return __longlong_as_double(((long long)rhi << 32) | (unsigned int)rlo);
-}
-__device__ __forceinline__ double lane_from_left(double x) /* lane l receives lane l-1 */
-{
-#ifdef MG3D_NO_DPP
-    return __shfl_up(x, 1, WAVE);
-#else
-    return dpp_move<0x138>(x); /* wave_shr:1 */
-#endif
-}
-__device__ __forceinline__ double lane_from_right(double x) /* lane l receives lane l+1 */
-{
-#ifdef MG3D_NO_DPP
-    return __shfl_down(x, 1, WAVE);
-#else
-    return dpp_move<0x130>(x); /* wave_shl:1 */
-#endif
-}
-
-/* Cache policy of the streams (compile-time MG3D_NT bits: 1 = u loads, 4 = d loads, 2 = u stores non-temporal, 8 = in
- * the pure residual launches (S = 0) the loads of the rows no other tile column reads; default 2).
- * The output is not read again before the next launch, a gigabyte later: written non-temporally it does not push the
- * halo rows the neighbouring tile columns are about to re-read out of L2 / the Infinity Cache (513^3: 265 -> 274
- * V-cycles/s).  Non-temporal LOADS lose exactly those halo re-reads (231 V-cycles/s); write-through stores
- * (`sc1`, `sc0 sc1`, `sc1 nt` by inline asm) measured 258-263.  Loading only the read-once rows non-temporally
- * helped the residual + restriction launch while it kept two planes in flight (0.64 -> 0.59 ms) and hurt the smoothing
- * launches (0.72 -> 0.88); with one plane in flight it no longer does (513^3: 0.566 against 0.554 ms without, 257^3:
- * 0.088 against 0.079), so bit 8 is off again. */
-typedef double v2d __attribute__((ext_vector_type(2)));
-#ifndef MG3D_NT
-#define MG3D_NT 2
-#endif
-template <int BIT> __device__ __forceinline__ double2 ld_stream(const double *p)
-{
-    if constexpr ((MG3D_NT & BIT) != 0) {
-        const v2d x = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
-        return make_double2(x.x, x.y);
-    } else {
-        return *reinterpret_cast<const double2 *>(p);
-    }
-}
-__device__ __forceinline__ void st_stream(double *p, double2 o)
-{
-#if (MG3D_NT & 2)
-    v2d x;
-    x.x = o.x;
-    x.y = o.y;
-    __builtin_nontemporal_store(x, reinterpret_cast<v2d *>(p));
-#else
-    *reinterpret_cast<double2 *>(p) = o;
-#endif
-}
-
-template <int S, int RES, int RJ, int NW, int PF, bool PRO, bool RST>
-__global__ void __launch_bounds__(NW *WAVE) sweep_kernel(SweepArgs a)
-{
-    using Sh = SweepShape<S, RES>;
-    constexpr int ST = Sh::ST, HJ = Sh::HJ, HI = Sh::HI;
-    constexpr int TJ = NW * RJ, VJ = TJ - 2 * HJ;
-    static_assert(RJ % 2 == 0, "RJ must be even (row parity of a wave's first row)");
-    static_assert(VJ > 0 && ST >= 1, "tile too small");
-    constexpr int STX = ST > 0 ? ST : 1;
-
-    /* edge rows exchanged between waves: [parity][wave][top/bottom][stage][lane] */
-    __shared__ double ex[2][NW][2][STX][WAVE];
-    __shared__ double red[NW];
-    __shared__ double2 rex[RES == 2 ? 2 : 1][RES == 2 ? NW : 1][RES == 2 ? WAVE : 1]; /* last row's r pair per wave */
-    /* PRO: three consecutive coarse planes of the tile's coarse footprint, [plane % 3][row][col] */
-    constexpr int CRW = PRO ? (NW * RJ) / 2 + 2 : 1, CCW = PRO ? WAVE + 2 : 1;
-    __shared__ double cpl[PRO ? 3 : 1][CRW][CCW];
-    /* RES == 2 behind colour passes: the r pairs a thread hands from one step's rows to the next step's restriction are
-     * written once and read once a whole step later -- parked in LDS (own rows only: no hazard, no second buffer) they
-     * free 4 x RJ VGPRs of a shape that otherwise spills inside the plane loop */
-    constexpr bool RPARK = RES == 2 && S > 0 && RJ >= 4;
-    __shared__ double2 rpark[RPARK ? NW * RJ : 1][RPARK ? WAVE : 1];
-    __shared__ double rkpark[RPARK ? NW * RJ : 1][RPARK ? WAVE : 1]; /* likewise the diff a row keeps for one step (rkeep) */
-
-    const Geom &g = a.g;
-    /* the wave index through readfirstlane: the compiler then knows that everything derived from it (the row
-     * flags below) is wave-uniform and keeps it in scalar registers and scalar branches instead of 64-bit lane
-     * masks -- the residual variants of this kernel were bound by the CU's one scalar ALU, not by memory */
-#ifndef MG3D_UNIFORM_W
-#define MG3D_UNIFORM_W 2 /* 0: never, 1: residual variants only, 2: every variant */
-#endif
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int w = (MG3D_UNIFORM_W == 2 || (MG3D_UNIFORM_W == 1 && RES != 0)) ? __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE)
-                                                                             : (int)(threadIdx.x / WAVE);
-    /* this block's work: in lock-step mode one segment (tile column t_lin, planes off .. off+len of the output range);
-     * in the balanced experiment its share [w0, w1) of the linearised (tile column, output plane) space, one or two
-     * segments.  The 64-bit divisions of the latter are ~1400 instructions of prologue (5-6 us per launch, a quarter
-     * of a whole launch on the levels below 129^3): they stay behind the mode test. */
-    const int nout = a.i_hi - a.i_lo;
-    int vb = blockIdx.x;
-    if (a.xcd_remap == 1) {
-        /* hardware deals blocks round-robin over the 8 XCDs (b % 8 names the XCD group, never which XCD); give
-         * each group a contiguous run of shares.  Speed only. */
-        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = vb & 7, idx = vb >> 3;
-        vb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
-    }
-    long long w0 = 0, w1 = 0;
-    int t_lin = 0, off = 0, len = 0;
-    const bool lockstep = a.CI > 0;
-    if (lockstep) {
-        /* block -> (tile column, i-chunk), tile fastest: all tile columns of a chunk march through the same planes at
-         * the same time, so a neighbour's halo rows are still in the Infinity Cache / L2 */
-        const int T = a.ntj * a.ntk;
-        int ch = vb / T;
-        int tl = vb - ch * T;
-        if (a.xcd_remap == 2) {
-            /* several rounds of blocks: inside every chunk's layer of T blocks, the blocks of one XCD group take a
-             * contiguous run of tile columns (renumbering the whole grid would scatter the first round over all
-             * chunks and break the lock-step).  Speed only. */
-            const int r0 = (ch * T) & 7, x = (r0 + tl) & 7;
-            int o = 0;
-            for (int y = 0; y < x; y++) {
-                const int first = (y - r0 + 8) & 7;
-                o += first < T ? (T - first + 7) >> 3 : 0;
-            }
-            tl = o + (tl - ((x - r0 + 8) & 7)) / 8;
-        }
-        t_lin = tl;
-        if (a.rev)
-            ch = (int)(gridDim.x / T) - 1 - ch;
-        off = ch * a.CI;
-        len = min(a.CI, nout - off);
-    } else {
-        const long long W = (long long)a.ntj * a.ntk * nout;
-        auto cut = [&](int k) -> long long {
-            long long x = W * k / gridDim.x;
-            const int r = (int)(x % nout);
-            if (r < a.snap)
-                x -= r;
-            else if (nout - r < a.snap)
-                x += nout - r;
-            return x;
-        };
-        w0 = cut(vb);
-        w1 = cut(vb + 1);
-    }
-    double acc = 0.;
-
-    for (bool more = true; more;) {
-    if (lockstep) {
-        more = false;
-    } else {
-        if (w0 >= w1)
-            break;
-        t_lin = (int)(w0 / nout);
-        off = (int)(w0 - (long long)t_lin * nout);
-        len = (int)min((long long)(nout - off), w1 - w0);
-        w0 += len;
-        more = w0 < w1;
-    }
-    const int tk = t_lin % a.ntk, tj = t_lin / a.ntk;
-
-    const int jt0 = tj * VJ - HJ, kt0 = tk * a.vk;
-    const int own_klo = tk == 0 ? 0 : kt0 + a.hk, own_khi = tk == a.ntk - 1 ? g.nk : kt0 + 2 * WAVE - a.hk;
-    const int jrow0 = jt0 + w * RJ;
-    const int kA = kt0 + 2 * lane; /* column 0 of the pair; column 1 = kA + 1 */
-    const int i_out0 = a.i_lo + off, i_out1 = i_out0 + len;
-    /* start plane: HI warm-up planes, one more if needed so that the column active at
-     * local step p in row rr is (p + rr) & 1 */
-    int i_s = i_out0 - HI;
-    i_s -= (g.ig0 + i_s + jt0 + 1 + a.c1) & 1;
-    /* the fused restriction finishes a coarse plane one fine plane after its centre, one step late */
-    const int nsteps = (i_out1 - 1 + ST) - i_s + 1 + (RES == 2 ? 2 : 0);
-
-    /* a plane in bytes fits 32 bits (the largest level the context admits, 2049^3: 34 MB a plane), so a plane's base is
-     * ONE 32 x 32 -> 64-bit scalar product, not the 64 x 64-bit one `long long * int` compiles to (eight scalar
-     * instructions a product, four products a step) */
-    const unsigned plane_bytes = (unsigned)(g.plane * (long long)sizeof(double));
-    /* plane ranges of this segment as (first plane, last - first); an empty range never matches */
-    const int upd_first = max(1, 1 - g.ig0), upd_last = min(g.ni - 2, g.N - 2 - g.ig0);
-    const int upd_lo = upd_last >= upd_first ? upd_first : 0x3fffffff;
-    const unsigned upd_span = upd_last >= upd_first ? (unsigned)(upd_last - upd_first) : 0u;
-    const int nrm_first = max(i_out0, a.acc_lo), nrm_last = min(i_out1, a.acc_hi) - 1;
-    const bool nrm_any = a.partials != nullptr && nrm_last >= nrm_first;
-    const int nrm_lo = nrm_any ? nrm_first : 0x3fffffff;
-    const unsigned nrm_span = nrm_any ? (unsigned)(nrm_last - nrm_first) : 0u;
-
-    /* RES == 2: fine planes qq (odd global index) behind which a coarse plane is complete AND to be stored:
-     * centre qq - 1 in [i_out0, i_out1), coarse plane (ig0 + qq - 1) / 2 in [1, Nc - 2] and in [ic_lo, ic_hi) locally */
-    const int rst_first = max(max(i_out0 + 1, 3 - g.ig0), 2 * (a.ic_lo + a.gc.ig0) + 1 - g.ig0);
-    const int rst_last = min(min(i_out1, 2 * a.gc.N - 3 - g.ig0), 2 * (a.ic_hi - 1 + a.gc.ig0) + 1 - g.ig0);
-    const int rst_lo = rst_last >= rst_first ? rst_first : 0x3fffffff;
-    const unsigned rst_span = rst_last >= rst_first ? (unsigned)(rst_last - rst_first) : 0u;
-
-    /* per-row / per-column masks */
-    bool row_in[RJ], row_upd[RJ], row_own[RJ], row_once[RJ];
-    /* byte offset of the thread's pair inside a plane: 32 bits (a plane is < 4 GB), so that an access is
-     * `uniform 64-bit plane base (SGPRs) + per-lane 32-bit offset` -- the saddr form of global_load / global_store: half
-     * the address registers and no 64-bit vector add per access */
-#ifndef MG3D_EDGE_UNCOND
-#define MG3D_EDGE_UNCOND 1 /* 1: the wave-edge LDS rows are read without a test in every shape (with MG3D_DLAG = 3 the
-                              * four-pass shape has the registers for it: 252 VGPRs, no scratch; 257^3 0.120 -> 0.108 ms,
-                              * 129^3 0.033 -> 0.028; with MG3D_DLAG = 2 it spills and loses 20 %) */
-#endif
-#ifndef MG3D_DLAG
-#define MG3D_DLAG 3 /* bit 0: the four-pass smoothing shape, bit 1: every other shape -- d trails u by one plane (load_plane); same-box A/B at 513^3: residual + restriction 0.551 -> 0.532 ms, prolongation + 2 passes 0.697 -> 0.679; the four-pass shape needs it to run without scratch once its edge rows are read unconditionally */
-#endif
-#ifndef MG3D_ADDR32
-#define MG3D_ADDR32 3 /* same bits: 32-bit per-lane offsets instead of 64-bit ones */
-#endif
-    constexpr int SHAPE_BIT = (S == 4 && (RES == 0 || RES == 3)) ? 0 : 1;
-    constexpr int DLAG = (MG3D_DLAG >> SHAPE_BIT) & 1;
-    constexpr bool A32 = ((MG3D_ADDR32 >> SHAPE_BIT) & 1) != 0;
-    typename std::conditional<A32, unsigned, long long>::type row_off[RJ];
-#pragma unroll
-    for (int rr = 0; rr < RJ; rr++) {
-        const int j = jrow0 + rr;
-        row_in[rr] = j >= 0 && j < g.nj;
-        row_upd[rr] = j >= 1 && j <= g.nj - 2;
-        row_own[rr] = row_in[rr] && j >= tj * VJ && j < (tj + 1) * VJ;
-        /* rows no other tile column reads (the outer HJ owned rows are the neighbours' halo) */
-        row_once[rr] = row_in[rr] && j >= tj * VJ + HJ && j < (tj + 1) * VJ - HJ;
-        /* loads are UNCONDITIONAL (load_plane): rows, columns and planes outside the level are clamped onto it.  What
-         * they deliver there is never used -- a point of the level only reads neighbours inside the level, and the points
-         * on its faces are passed through, not computed -- so clamping replaces a guard (two scalar ANDs, an EXEC save, a
-         * branch and a restore per row and field: half of the step's scalar instructions) by nothing */
-        const int jc = j < 0 ? 0 : (j >= g.nj ? g.nj - 1 : j), kc = kA > g.pitch - 2 ? g.pitch - 2 : kA;
-        row_off[rr] = (decltype(row_off[0] + 0))(((long long)g.pitch * jc + kc) * (long long)sizeof(double));
-    }
-    const bool col_in[2] = {kA >= 0 && kA < g.nk, kA + 1 >= 0 && kA + 1 < g.nk};
-    const bool col_upd[2] = {kA >= 1 && kA <= g.nk - 2, kA + 1 >= 1 && kA + 1 <= g.nk - 2};
-    const bool pair_own = kA >= own_klo && kA < own_khi && col_in[0];
-    /* lane masks used inside the plane loop (the row flags are wave-uniform scalars) */
-    const bool own_upd[2] = {pair_own && col_upd[0], pair_own && col_upd[1]};
-    const bool own_both = own_upd[0] && own_upd[1], own_only0 = own_upd[0] && !col_upd[1],
-               own_only1 = own_upd[1] && !col_upd[0];
-    const bool k_edge_tile = tk == 0 || tk == a.ntk - 1; /* only there a pair can have one updatable column */
-    /* RES == 2: the coarse points this thread completes -- rows centred on its even rows, its even column */
-    bool crow_ok[RJ / 2];
-    long long dc_off[RJ / 2];
-    const bool ccol_ok = pair_own && (kA >> 1) >= 1 && (kA >> 1) <= a.gc.nk - 2;
-#pragma unroll
-    for (int c = 0; c < RJ / 2; c++) {
-        const int jc = (jrow0 + 2 * c) >> 1;
-        crow_ok[c] = row_own[2 * c] && jc >= 1 && jc <= a.gc.nj - 2;
-        dc_off[c] = (long long)a.gc.pitch * jc + (kA >> 1);
-    }
-
-    /* pipeline state (see header).  last[rr][s][c]: newest stage-s output of column c */
-    double last[RJ][STX][2], in_prev[RJ][2], dring[RJ][ST + 1][2], rkeep[RJ];
-    double2 cur_v[RJ], nxt_v[PF][RJ], nxt_d[PF][RJ]; /* planes in flight from HBM: PF ahead */
-#pragma unroll
-    for (int rr = 0; rr < RJ; rr++) {
-#pragma unroll
-        for (int s = 0; s < STX; s++)
-            last[rr][s][0] = last[rr][s][1] = 0.;
-#pragma unroll
-        for (int s = 0; s <= ST; s++)
-            dring[rr][s][0] = dring[rr][s][1] = 0.;
-        in_prev[rr][0] = in_prev[rr][1] = 0.;
-        rkeep[rr] = 0.;
-        cur_v[rr] = make_double2(0., 0.);
-    }
-    double2 rlag[RJ];           /* RES == 2: r pairs of the plane finished by the previous step */
-    double racc[RJ / 2];        /* running 27-point sums, one per coarse row centred in this thread's rows */
-#pragma unroll
-    for (int rr = 0; rr < RJ; rr++) {
-        rlag[rr] = make_double2(0., 0.);
-        if constexpr (RPARK)
-            rpark[w * RJ + rr][lane] = make_double2(0., 0.), rkpark[w * RJ + rr][lane] = 0.;
-    }
-#pragma unroll
-    for (int c = 0; c < RJ / 2; c++)
-        racc[c] = 0.;
-
-    /* u of plane i and d of plane i - 1: no stage reads d of the plane that has just arrived (stage s works on plane
-     * i - s, s >= 1), so its load trails u's by one step and lands straight in the first slot of the d window -- one
-     * slot (2 x RJ doubles: 16 VGPRs of a register file that every shape fills) less than loading both together */
-    auto load_plane = [&](int i, double2(&vv)[RJ], double2(&dd)[RJ]) {
-#ifdef MG3D_EXPERIMENT_SAME_PLANE /* timing experiment only (wrong results): every load hits the same, cached, plane */
-        const int iu = i_s < 0 ? 0 : i_s, id = iu;
-        (void)i;
-#else
-        const int iu = i < 0 ? 0 : (i >= g.ni ? g.ni - 1 : i), id = i - DLAG < 0 ? 0 : (i - DLAG >= g.ni ? g.ni - 1 : i - DLAG);
-#endif
-        /* plane bases in bytes, uniform: one scalar 64-bit product per plane, not one re-materialised per row */
-        long long pbase = (long long)((unsigned long long)plane_bytes * (unsigned)iu), pbase_d = (long long)((unsigned long long)plane_bytes * (unsigned)id);
-        asm volatile("" : "+s"(pbase), "+s"(pbase_d));
-        const char *ubase = reinterpret_cast<const char *>(a.vin) + pbase, *dbase = reinterpret_cast<const char *>(a.d) + pbase_d;
-        /* vin == NULL: the input field is identically zero (a coarse level's initial guess, mg_3d.h:1258-1259) --
-         * neither zeroed in memory beforehand nor read */
-        const bool have_u = a.vin != nullptr; /* uniform */
-        /* (one uniform test for the whole plane, not one per row: the rows' loads stay a straight line) */
-        if (have_u) {
-#pragma unroll
-            for (int rr = 0; rr < RJ; rr++) {
-                const double *pu = reinterpret_cast<const double *>(ubase + row_off[rr]);
-#if (MG3D_NT & 8)
-                if (S == 0 && row_once[rr]) /* wave-uniform */
-                    vv[rr] = ld_stream<8>(pu);
-                else
-#endif
-                    vv[rr] = ld_stream<1>(pu);
-            }
-        } else {
-#pragma unroll
-            for (int rr = 0; rr < RJ; rr++)
-                vv[rr] = make_double2(0., 0.);
-        }
-#pragma unroll
-        for (int rr = 0; rr < RJ; rr++) {
-            const double *pd = reinterpret_cast<const double *>(dbase + row_off[rr]);
-#if (MG3D_NT & 8)
-            if (S == 0 && row_once[rr])
-                dd[rr] = ld_stream<8>(pd);
-            else
-#endif
-                dd[rr] = ld_stream<4>(pd);
-        }
-    };
-
-    /* ---- PRO: coarse planes staged in LDS.  Plane c (local coarse index) lives in slot c mod 3. */
-    const int jcb = jt0 >> 1, kcb = kt0 >> 1; /* coarse origin of the tile (jt0, kt0 are even) */
-    auto coarse_of = [&](int i) { /* lower coarse parent plane (local) of fine local plane i */
-        const int ig = g.ig0 + i, oi = ig & 1;
-        return (ig - oi) / 2 - a.gce.ig0;
-    };
-    auto slot_of = [](int c) { return ((c % 3) + 3) % 3; };
-    constexpr int CPT = PRO ? (CRW * CCW + NW * WAVE - 1) / (NW * WAVE) : 1; /* staged values per thread */
-    auto coarse_fetch = [&](int c, double(&buf)[CPT]) {
-        /* unconditional, from clamped indices (as load_plane): a fine point of the level has its parents inside the
-         * coarse level, what is staged for positions outside it is never used */
-        const int cc = c < 0 ? 0 : (c >= a.gce.ni ? a.gce.ni - 1 : c);
-        const long long cbase = a.gce.plane * cc;
-#pragma unroll
-        for (int t = 0; t < CPT; t++) {
-            int idx = threadIdx.x + t * NW * WAVE;
-            idx = idx < CRW * CCW ? idx : CRW * CCW - 1;
-            const int row = idx / CCW, col = idx - row * CCW;
-            int jc = jcb + row, kc = kcb + col;
-            jc = jc < 0 ? 0 : (jc >= a.gce.nj ? a.gce.nj - 1 : jc);
-            kc = kc < 0 ? 0 : (kc >= a.gce.nk ? a.gce.nk - 1 : kc);
-            buf[t] = a.ec[cbase + (long long)a.gce.pitch * jc + kc];
-        }
-    };
-    auto coarse_put = [&](int c, const double(&buf)[CPT]) {
-        const int sl = slot_of(c);
-#pragma unroll
-        for (int t = 0; t < CPT; t++) {
-            const int idx = threadIdx.x + t * NW * WAVE;
-            if (idx < CRW * CCW)
-                (&cpl[sl][0][0])[idx] = buf[t];
-        }
-    };
-    int have_hi = 0; /* highest coarse plane staged so far */
-    if constexpr (PRO) {
-        double buf[CPT];
-        const int c0 = coarse_of(i_s);
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            coarse_fetch(c0 + c, buf);
-            coarse_put(c0 + c, buf);
-        }
-        have_hi = c0 + 1;
-        __syncthreads();
-    }
-
-    /* prime the prefetch queue with planes i_s .. i_s+PF-1 */
-#pragma unroll
-    for (int f = 0; f < PF; f++)
-        load_plane(i_s + f, nxt_v[f], nxt_d[f]);
-
-    auto step = [&](int pl, auto par_c) {
-        constexpr int PAR = decltype(par_c)::value;
-        const int i = i_s + pl; /* local plane just arrived */
-        const int par = pl & 1;
-        /* current plane <- head of the prefetch queue, then request plane i+PF */
-#ifndef MG3D_PIN_LOADS
-#define MG3D_PIN_LOADS 0
-#endif
-        if constexpr (MG3D_PIN_LOADS != 0) {
-            /* The plane requested a step ago is first TOUCHED here, behind the barrier: an empty volatile asm that takes its
-             * registers.  Without it the scheduler hoists this step's first copies of those registers (plain VALU moves,
-             * free to cross an s_barrier) into the tail of the previous step, and the wait for the load goes with them:
-             * the listing showed `s_waitcnt vmcnt(7) .. (4)` strung through the step that had just issued the request --
-             * a plane was in flight for a fraction of a step, not for one. */
-            constexpr int SLOT = PF == 2 ? PAR : 0;
-#pragma unroll
-            for (int rr = 0; rr < RJ; rr++)
-                asm volatile("" : "+v"(nxt_v[SLOT][rr].x), "+v"(nxt_v[SLOT][rr].y), "+v"(nxt_d[SLOT][rr].x), "+v"(nxt_d[SLOT][rr].y));
-        }
-        if constexpr (PF == 2) {
-            /* two planes in flight as a RING indexed by the step's parity (a template argument), not a queue that shifts:
-             * shifting copies the registers of the plane still in flight, and a copy has to wait for its load -- with
-             * the queue a "second plane in flight" was never in flight for more than one step */
-#pragma unroll
-            for (int rr = 0; rr < RJ; rr++) {
-                cur_v[rr] = nxt_v[PAR][rr];
-                dring[rr][0][0] = nxt_d[PAR][rr].x;
-                dring[rr][0][1] = nxt_d[PAR][rr].y;
-            }
-#ifndef MG3D_PF2_LATE
-#define MG3D_PF2_LATE 0 /* 1: the ring's loads are issued at the END of the step, behind its stores (see there) */
-#endif
-            if constexpr (MG3D_PF2_LATE == 0)
-                load_plane(i + PF, nxt_v[PAR], nxt_d[PAR]);
-        } else {
-#pragma unroll
-            for (int rr = 0; rr < RJ; rr++) {
-                cur_v[rr] = nxt_v[0][rr];
-                dring[rr][0][0] = nxt_d[0][rr].x;
-                dring[rr][0][1] = nxt_d[0][rr].y;
-#pragma unroll
-                for (int f = 0; f + 1 < PF; f++) {
-                    nxt_v[f][rr] = nxt_v[f + 1][rr];
-                    nxt_d[f][rr] = nxt_d[f + 1][rr];
-                }
-            }
-            load_plane(i + PF, nxt_v[PF - 1], nxt_d[PF - 1]);
-        }
-        double cbuf[CPT];
-        bool stage_new = false;
-        if constexpr (PRO) {
-            /* the next step needs coarse planes up to coarse_of(i+1)+1: fetch one now, publish before the barrier */
-            stage_new = coarse_of(i + 1) + 1 > have_hi;
-            if (stage_new)
-                coarse_fetch(have_hi + 1, cbuf);
-            /* v_in = u + P(ec): parents summed in the reference's order per parity class (see prolong_kernel) */
-            const int ig = g.ig0 + i, oi = ig & 1;
-            const int s0 = slot_of(coarse_of(i)), s1 = slot_of(coarse_of(i) + 1);
-#pragma unroll
-            for (int rr = 0; rr < RJ; rr++) {
-                const int oj = rr & 1; /* jrow0 is even */
-                const int lr = (w * RJ + rr) >> 1;
-                const double e000 = cpl[s0][lr][lane], e001 = cpl[s0][lr][lane + 1];
-                double t0, t1;
-                if (!oi && !oj) {
-                    t0 = e000;
-                    t1 = (e000 + e001) * 0.5;
-                } else if (!oi) {
-                    const double e010 = cpl[s0][lr + 1][lane], e011 = cpl[s0][lr + 1][lane + 1];
-                    t0 = (e000 + e010) * 0.5;
-                    t1 = (((e000 + e010) + e001) + e011) * 0.25;
-                } else if (!oj) {
-                    const double e100 = cpl[s1][lr][lane], e101 = cpl[s1][lr][lane + 1];
-                    t0 = (e000 + e100) * 0.5;
-                    t1 = (((e000 + e100) + e001) + e101) * 0.25;
-                } else {
-                    const double e010 = cpl[s0][lr + 1][lane], e011 = cpl[s0][lr + 1][lane + 1];
-                    const double e100 = cpl[s1][lr][lane], e101 = cpl[s1][lr][lane + 1];
-                    const double e110 = cpl[s1][lr + 1][lane], e111 = cpl[s1][lr + 1][lane + 1];
-                    t0 = (((e000 + e010) + e100) + e110) * 0.25;
-                    double t = e000 + e001;
-                    t = t + e010;
-                    t = t + e011;
-                    t = t + e100;
-                    t = t + e101;
-                    t = t + e110;
-                    t = t + e111;
-                    t1 = t * 0.125;
-                }
-                cur_v[rr].x += t0;
-                cur_v[rr].y += t1;
-            }
-        }
-
-        /* rows of the neighbouring waves, written at the end of the previous step */
-        double e_top[STX], e_bot[STX];
-#pragma unroll
-        for (int s = 0; s < STX; s++) {
-            /* the first / last wave has no neighbour: its outermost row is the tile's outermost halo row (or lies outside
-             * the grid), whose results are never used -- it reads its own row instead of branching around the read.
-             * Not in the two shapes that sit at 256 VGPRs: there the eight unconditional reads at the top of the step
-             * lengthen live ranges into scratch spills inside the plane loop (measured 0.68 -> 0.94 ms at 513^3). */
-            if constexpr (MG3D_EDGE_UNCOND || (S < 4 && (RES != 2 || PF == 1))) {
-                e_top[s] = ex[par ^ 1][w > 0 ? w - 1 : 0][1][s][lane];
-                e_bot[s] = ex[par ^ 1][w < NW - 1 ? w + 1 : NW - 1][0][s][lane];
-            } else {
-                e_top[s] = (w > 0) ? ex[par ^ 1][w - 1][1][s][lane] : 0.;
-                e_bot[s] = (w < NW - 1) ? ex[par ^ 1][w + 1][0][s][lane] : 0.;
-            }
-        }
-        /* store planes, bases in bytes */
-        /* (planes outside the level: any product will do, the stores are guarded by v_ok / r_ok) */
-        long long vbase = (long long)((unsigned long long)plane_bytes * (unsigned)(i - S)), rbase = (long long)((unsigned long long)plane_bytes * (unsigned)(i - ST));
-        asm volatile("" : "+s"(vbase), "+s"(rbase));
-        /* which planes may be updated (global boundary planes / slab halos are not), which enter the norm, which are
-         * stored: each a range of planes fixed per segment (upd_lo .. below), tested with ONE unsigned compare
-         * (q - lo <= span) instead of four signed ones and the branches a short-circuit turns them into */
-        bool pl_upd[STX + 1], acc_ok[STX + 1];
-#pragma unroll
-        for (int s = 1; s <= ST; s++) {
-            const int q = i - s;
-            pl_upd[s] = (unsigned)(q - upd_lo) <= upd_span;
-            acc_ok[s] = (RES == 1 || RES == 3) ? (unsigned)(q - nrm_lo) <= nrm_span : false; /* planes that enter the norm */
-        }
-        /* this step's store planes lie in the output range (wave-uniform, once per step, not once per row) */
-        const bool v_ok = (unsigned)(i - S - i_out0) < (unsigned)len;
-        const bool r_ok = RES == 1 ? (a.r != nullptr) & ((unsigned)(i - ST - i_out0) < (unsigned)len) & pl_upd[ST] : false;
-/* wave-uniform tests joined without short-circuit where that is free (one scalar AND instead of a branch per operand);
- * the restriction shape spills with it (scratch 36 -> 96 bytes, 0.59 -> 1.0 ms), the pure smoothers gain nothing */
-#define MG3D_AND(x, y) ((RES == 1 || RES == 3) ? ((x) & (y)) : ((x) && (y)))
-
-        if constexpr (RES == 2) {
-            /* (BEFORE this step's rows: they overwrite rlag in place -- a second set of r pairs would be 4 x RJ VGPRs)
-             * Full weighting of plane qq = i-ST-1 (its r pairs are in rlag; the row above this wave's first
-             * row was published by the wave above at the end of the previous step).  Coarse row centres sit
-             * on this thread's even rows rr = 0, 2, ..; coarse column = this lane's even column kA.  The
-             * reference adds the 27 products r*w in the order ti, tj, tk (mg_3d.h:980-988): planes arrive
-             * in ti order, and inside a plane the nine terms below are tj-major, tk-minor. */
-            const int qq = i - ST - 1, qg = g.ig0 + qq;
-            const bool odd = (qg & 1) != 0;
-            const double wi = odd ? 0.25 : 0.5;
-            const double2 top = rex[par ^ 1][w > 0 ? w - 1 : 0][lane]; /* wave 0: a halo row's sum, never stored */
-#pragma unroll
-            for (int c = 0; c < RJ / 2; c++) {
-                double2 r0, r1, r2;
-                if constexpr (RPARK) {
-                    r0 = c == 0 ? top : rpark[w * RJ + 2 * c - 1][lane];
-                    r1 = rpark[w * RJ + 2 * c][lane];
-                    r2 = rpark[w * RJ + 2 * c + 1][lane];
-                } else {
-                    r0 = c == 0 ? top : rlag[2 * c - 1];
-                    r1 = rlag[2 * c];
-                    r2 = rlag[2 * c + 1];
-                }
-                const double l0 = lane_from_left(r0.y), l1 = lane_from_left(r1.y), l2 = lane_from_left(r2.y);
-                const double p[9] = {l0 * (wi * 0.25 * 0.25), r0.x * (wi * 0.25 * 0.5), r0.y * (wi * 0.25 * 0.25),
-                                     l1 * (wi * 0.5 * 0.25),  r1.x * (wi * 0.5 * 0.5),  r1.y * (wi * 0.5 * 0.25),
-                                     l2 * (wi * 0.25 * 0.25), r2.x * (wi * 0.25 * 0.5), r2.y * (wi * 0.25 * 0.25)};
-                double run = racc[c];
-#pragma unroll
-                for (int t = 0; t < 9; t++)
-                    run = run + p[t];
-                if (odd) {
-                    /* qq is the ti = 2 plane of coarse plane (qg-1)/2 and the ti = 0 plane of (qg+1)/2.  The coarse plane
-                     * is stored when its centre plane qq - 1 lies in this segment's output range, it is an interior
-                     * plane of the coarse level and one this launch is to write: one range of qq (rst_lo, rst_span) */
-                    if (((unsigned)(qq - rst_lo) <= rst_span) & crow_ok[c]) { /* wave-uniform */
-                        const int icl = ((qg - 1) >> 1) - a.gc.ig0;
-                        if (ccol_ok)
-                            a.dc[a.gc.plane * icl + dc_off[c]] = run;
-                    }
-                    double fresh = 0.;
-#pragma unroll
-                    for (int t = 0; t < 9; t++)
-                        fresh = fresh + p[t];
-                    racc[c] = fresh;
-                } else {
-                    racc[c] = run;
-                }
-            }
-        }
-#pragma unroll
-        for (int rr = 0; rr < RJ; rr++) {
-            const int X = (PAR + rr) & 1; /* active column of this row at this step */
-            double nw[STX + 1];
-            nw[0] = X ? cur_v[rr].y : cur_v[rr].x;
-            double diffs[2] = {0., 0.};
-#pragma unroll
-            for (int s = 1; s <= ST; s++) {
-                const double up = last[rr][s - 1][X]; /* plane q-1: two steps old */
-                const double dn = nw[s - 1];          /* plane q+1: this step */
-                const double jm = (rr > 0) ? last[rr - 1][s - 1][X] : e_top[s - 1];
-                const double jp = (rr < RJ - 1) ? last[rr + 1][s - 1][X] : e_bot[s - 1];
-                double km, kp;
-                if (X == 0) {
-                    km = lane_from_left(last[rr][s - 1][1]);
-                    kp = last[rr][s - 1][1];
-                } else {
-                    km = last[rr][s - 1][0];
-                    kp = lane_from_right(last[rr][s - 1][0]);
-                }
-                const double dd = dring[rr][s - DLAG][X]; /* DLAG: slot 0 = plane i - 1 (load_plane) */
-                const double center = (s == 1) ? in_prev[rr][X] : last[rr][s - 2][X];
-                double sum = up + dn;
-                sum = sum + jm;
-                sum = sum + jp;
-                sum = sum + km;
-                sum = sum + kp;
-                /* `&`, not `&&`: a short-circuit on the wave-uniform part turns every update into a scalar branch around
-                 * it (78 branches a step); the select costs nothing and leaves one basic block to schedule */
-                const bool updu = row_upd[rr] & pl_upd[s]; /* wave-uniform part of "this point is updated" */
-                if (s <= S) {
-#ifdef MG3D_EXPERIMENT_DROP_FLOPS /* timing experiment only (wrong results): is the step bound by its fp64 operations? */
-                    const double val = sum - dd;
-#else
-                    const double val = a.sixth * (sum - a.hSq * dd); /* mg_3d.h:438-443 */
-#endif
-                    nw[s] = (updu & col_upd[X]) ? val : center;
-                    if constexpr (RES == 3) {
-                        /* The tap: the residual norm of the state BETWEEN pass S/2 and pass S/2 + 1 without a stage of its
-                         * own.  The colour pass S/2 has just updated: its residual uses that pass's neighbour sum (as
-                         * below).  The other colour: pass S/2 + 1 is about to update it from exactly the six neighbours
-                         * (all of the colour pass S/2 + 1 leaves alone) and the centre (untouched by pass S/2) that the
-                         * residual of the tapped state is made of -- mg_3d.h:819-821 on the sum the update forms anyway. */
-                        if (s == S / 2 || s == S / 2 + 1) {
-                            const double diff = dd - a.invHsq * (sum - 6 * (s == S / 2 ? nw[s] : center));
-                            if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
-                                acc += own_upd[X] ? diff * diff : 0.;
-                        }
-                    }
-                    if ((RES == 1 || RES == 2) && s == S) { /* residual of the point just updated: same six neighbours */
-                        const double diff = dd - a.invHsq * (sum - 6 * nw[s]); /* mg_3d.h:819-821 */
-                        diffs[0] = diff;
-                        /* adding +0 leaves a sum of squares unchanged: a select, not a branch */
-                        if constexpr (RES == 1)
-                            if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
-                                acc += own_upd[X] ? diff * diff : 0.;
-                    }
-                } else {
-                    const double diff = dd - a.invHsq * (sum - 6 * center); /* mg_3d.h:819-821 */
-                    nw[s] = center;
-                    diffs[S > 0 ? 1 : s - 1] = diff;
-                    if constexpr (RES == 1)
-                        if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
-                            acc += own_upd[X] ? diff * diff : 0.;
-                }
-            }
-            /* ---- stores: v' of plane i-S, r of plane i-S-2 (pairs complete at this step) */
-            if constexpr (S > 0) {
-                if (MG3D_AND(v_ok, row_own[rr])) { /* wave-uniform */
-                    const double other = last[rr][S - 1][X ^ 1]; /* finished one step ago */
-                    double2 o;
-                    o.x = X ? other : nw[S];
-                    o.y = X ? nw[S] : other;
-                    if (pair_own)
-                        st_stream(reinterpret_cast<double *>(reinterpret_cast<char *>(a.vout) + vbase + row_off[rr]), o);
-                }
-            }
-            if constexpr (RES == 2 || (RES == 1 && RST)) { /* RST = false: the norm only, r is not assembled */
-                /* column X: the residual-only stage now; column X^1: the previous step's diff */
-                double2 o;
-                const double kept = RPARK ? rkpark[w * RJ + rr][lane] : rkeep[rr];
-                o.x = X ? kept : diffs[1];
-                o.y = X ? diffs[1] : kept;
-                if constexpr (RES == 2) { /* read by the NEXT step's restriction */
-                    if constexpr (RPARK)
-                        rpark[w * RJ + rr][lane] = o;
-                    else
-                        rlag[rr] = o;
-                    if (rr == RJ - 1)
-                        rex[par][w][lane] = o;
-                }
-                if (RES == 1 && MG3D_AND(MG3D_AND(r_ok, row_own[rr]), row_upd[rr])) { /* wave-uniform */
-                    double *dst = reinterpret_cast<double *>(reinterpret_cast<char *>(a.r) + rbase + row_off[rr]);
-                    if (own_both)
-                        *reinterpret_cast<double2 *>(dst) = o;
-                    if (k_edge_tile) { /* boundary entries of r are never written (mg_3d.h:824-825) */
-                        if (own_only0)
-                            dst[0] = o.x;
-                        if (own_only1)
-                            dst[1] = o.y;
-                    }
-                }
-                if constexpr (RPARK)
-                    rkpark[w * RJ + rr][lane] = diffs[0];
-                else
-                    rkeep[rr] = diffs[0];
-            }
-            /* ---- commit this row's new outputs */
-            in_prev[rr][0] = cur_v[rr].x;
-            in_prev[rr][1] = cur_v[rr].y;
-#pragma unroll
-            for (int s = 0; s < ST; s++)
-                last[rr][s][X] = nw[s];
-        }
-        /* age the d window (slots 0 .. ST-1 = planes i-1 .. i-ST) */
-#pragma unroll
-        for (int rr = 0; rr < RJ; rr++)
-#pragma unroll
-            for (int s = ST - DLAG; s >= 1; s--) {
-                dring[rr][s][0] = dring[rr][s - 1][0];
-                dring[rr][s][1] = dring[rr][s - 1][1];
-            }
-        /* PF == 2: request plane i + 2 now, BEHIND this step's stores.  vmcnt counts loads and stores in issue order:
-         * with the request at the top of the step the compiler's wait for the plane the NEXT step needs also covers this
-         * step's younger stores and, piecemeal, the request itself -- a plane was never in flight for a whole step.  Issued
-         * last, the only operations younger than the plane a step waits for are one step's stores and one request:
-         * the wait (vmcnt(12)) leaves exactly that request in flight. */
-        if constexpr (PF == 2 && MG3D_PF2_LATE != 0)
-            load_plane(i + PF, nxt_v[PAR], nxt_d[PAR]);
-        /* publish this wave's edge rows for the next step */
-#pragma unroll
-        for (int s = 0; s < ST; s++) {
-            ex[par][w][0][s][lane] = last[0][s][(PAR + 0) & 1];
-            ex[par][w][1][s][lane] = last[RJ - 1][s][(PAR + RJ - 1) & 1];
-        }
-        if constexpr (PRO) {
-            if (stage_new) {
-                coarse_put(have_hi + 1, cbuf);
-                have_hi++;
-            }
-        }
-        __syncthreads();
-    };
-
-    int pl = 0;
-    for (; pl + 1 < nsteps; pl += 2) {
-        step(pl, std::integral_constant<int, 0>{});
-        step(pl + 1, std::integral_constant<int, 1>{});
-    }
-    if (pl < nsteps)
-        step(pl, std::integral_constant<int, 0>{});
-    } /* segments */
-
-    if ((RES == 1 || RES == 3) && a.partials) {
-#pragma unroll
-        for (int off = WAVE / 2; off > 0; off >>= 1)
-            acc += __shfl_down(acc, off, WAVE);
-        if (lane == 0)
-            red[w] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.;
-            for (int x = 0; x < NW; x++)
-                t += red[x];
-            a.partials[blockIdx.x] = t;
-        }
-    }
-}
+#include "mg3d_sweep_kernel.h"
 
 /* -------------------------------------------------------------------- launch */
 /* the first-use measurement of chunk lengths blocks the host (hipEventSynchronize) in the middle of an enqueue: fine for
@@ -858,7 +89,7 @@ static int device_cus() /* of the CURRENT device (a process may drive several: m
     return it->second;
 }
 
-template <int S, int RES, int RJ, int NW, int PF, bool PRO = false, bool RST = true>
+template <int S, int RES, int RJ, int NW, int PF, bool PRO = false, bool RST = true, int DP = 0, int TAP = -1>
 static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
 {
     using Sh = SweepShape<S, RES>;
@@ -964,7 +195,7 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
         a.xcd_remap = xcd_forced ? atoi(xcd_env) : nb < 64 ? 0 : nb <= ncu ? 1 : 2;
     };
     auto launch = [&]() {
-        hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO, RST>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
+        hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO, RST, DP, TAP>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
     };
     if (getenv("MG3D_SWEEP_BALANCED") && getenv("MG3D_SWEEP_BALANCED")[0] == '1') {
         /* experiment: equal shares of the linearised (tile column, plane) space, one block per CU, no lock-step */
@@ -1229,7 +460,7 @@ static int sweep_impl(const Geom &g, const double *vin, const double *d, double 
         return dispatch<4, 3>(a, env_cfg({4, 8, 1}), max_partials, s);
     }
     if (ec) { /* prolongation fused into the input: 4- and 2-pass smoothing launches */
-        if (dc || residual || (g.nj & 1) == 0)
+        if (dc || residual || (g.nj & 1) == 0 || c1 != 0) /* (c1: the kernel derives the plane parity from it, see PRO) */
             return -1;
         if (S == 4) /* small levels: two rows per thread (no spills, 8 owned rows of 16); else the opt-in four-row shape */
             return g.N <= k_sweep_small_max() ? launch_sweep<4, 0, 2, 8, 2, true>(a, max_partials, s)
@@ -1269,6 +500,91 @@ static int sweep_impl(const Geom &g, const double *vin, const double *d, double 
     if (S == 0 && residual)
         return dispatch<0, 1>(a, env_cfg({4, 8, 1}), max_partials, s);
     return -1;
+}
+
+
+/* ---------------------------------------------------------------------------------------------- one launch per leg
+ * The legs of a V(2,2) cycle on a level as ONE launch each (mg3d_ctx.hip, "two launches per level"): the level streams
+ * through the chip twice per cycle instead of three or four times.  The windows are five to six planes deep: they fit at
+ * one wave per SIMD (eight rows per thread, 256 threads, the 512-register budget) with the oldest slots of the d window
+ * parked in LDS (DP).
+ *   down: S colour passes starting with colour c1 (4: red first, mg_3d.h:657; 3: black first -- the cycle's first red
+ *         pass is the identity behind the previous cycle's last red pass), the residual (:1294) and its full-weighting
+ *         restriction into the interior of the coarse right-hand side (:1310).  partials != NULL (S = 3 only): the sum of
+ *         diff^2 of the INCOMING state over the colour the first pass updates -- the second half of the previous cycle's
+ *         residual norm (:1354), see k_sweep_leg_up.
+ *   up:   prolongation (:1331) folded into the loads, four post-smoothing passes black, red, black, red (:1341).
+ *         partials != NULL: the sum of diff^2 of the RESULT over the colour the last pass has updated (red) -- the first
+ *         half of the cycle's residual norm; the other half is formed by the next down-leg (or by a norm-only launch). */
+#ifndef MG3D_LEG_DP_UP
+#define MG3D_LEG_DP_UP 3
+#endif
+#ifndef MG3D_LEG_DP_DOWN3
+#define MG3D_LEG_DP_DOWN3 2
+#endif
+#ifndef MG3D_LEG_DP_DOWN4
+#define MG3D_LEG_DP_DOWN4 1
+#endif
+
+static void leg_args(SweepArgs &a, const Geom &g, const double *vin, const double *d, double *vout, double *partials, double h,
+                     int c1, int i_lo, int i_hi, int acc_lo, int acc_hi)
+{
+    a.g = g;
+    a.vin = vin;
+    a.d = d;
+    a.vout = vout;
+    a.r = nullptr;
+    a.partials = partials;
+    a.hSq = h * h;           /* mg_3d.h:644 */
+    a.sixth = 1. / 6;        /* mg_3d.h:646 */
+    a.invHsq = 1. / (h * h); /* mg_3d.h:797 */
+    a.c1 = c1;
+    a.i_lo = i_lo >= 0 ? i_lo : 0;
+    a.i_hi = i_hi >= 0 ? i_hi : g.ni;
+    a.acc_lo = acc_lo;
+    a.acc_hi = acc_hi < 0 ? g.ni : acc_hi;
+    a.ec = nullptr;
+    a.gce = g;
+    a.gc = g;
+    a.dc = nullptr;
+    a.ic_lo = a.ic_hi = 0;
+}
+
+int k_sweep_leg_down(const Geom &g, const double *vin, const double *d, double *vout, const Geom &gc, double *dc, double h, int S,
+                     double *partials, int max_partials, hipStream_t s, int acc_lo, int acc_hi, int ic_lo, int ic_hi, int i_lo,
+                     int i_hi)
+{
+    SweepArgs a;
+    leg_args(a, g, vin, d, vout, partials, h, S == 4 ? 1 : 0, i_lo, i_hi, acc_lo, acc_hi);
+    if (a.i_hi <= a.i_lo)
+        return 0;
+    a.gc = gc;
+    a.dc = dc;
+    a.ic_lo = ic_lo >= 0 ? ic_lo : 0;
+    a.ic_hi = ic_hi >= 0 ? ic_hi : gc.ni;
+    if (S == 4 && !partials)
+        return launch_sweep<4, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN4, -1>(a, max_partials, s);
+    if (S == 3 && partials)
+        return launch_sweep<3, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN3, 0>(a, max_partials, s);
+    if (S == 3)
+        return launch_sweep<3, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN3, -1>(a, max_partials, s);
+    return -1;
+}
+
+int k_sweep_leg_up(const Geom &g, const double *vin, const double *d, double *vout, const Geom &gce, const double *ec, double h,
+                   double *partials, int max_partials, hipStream_t s, int acc_lo, int acc_hi, int i_lo, int i_hi)
+{
+    if ((g.nj & 1) == 0)
+        return -1;
+    SweepArgs a;
+    leg_args(a, g, vin, d, vout, partials, h, 0, i_lo, i_hi, acc_lo, acc_hi);
+    if (a.i_hi <= a.i_lo)
+        return 0;
+    a.ec = ec;
+    a.gce = gce;
+    if (partials)
+        return launch_sweep<4, 0, 8, 4, 1, true, true, MG3D_LEG_DP_UP, 4>(a, max_partials, s);
+    return launch_sweep<4, 0, 8, 4, 1, true, true, MG3D_LEG_DP_UP, -1>(a, max_partials, s);
 }
 
 int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
