@@ -89,7 +89,7 @@ static int device_cus() /* of the CURRENT device (a process may drive several: m
     return it->second;
 }
 
-template <int S, int RES, int RJ, int NW, int PF, bool PRO = false, bool RST = true, int DP = 0, int TAP = -1>
+template <int S, int RES, int RJ, int NW, int PF, bool PRO = false, bool RST = true, int DP = 0, int TAP = -1, int C1K = -1>
 static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
 {
     using Sh = SweepShape<S, RES>;
@@ -195,7 +195,10 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
         a.xcd_remap = xcd_forced ? atoi(xcd_env) : nb < 64 ? 0 : nb <= ncu ? 1 : 2;
     };
     auto launch = [&]() {
-        hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO, RST, DP, TAP>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
+        static_assert(C1K < 0 || !PRO || C1K == 0, "PRO launches are post-smoothers");
+        if (C1K >= 0 && a.c1 != C1K)
+            return;
+        hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO, RST, DP, TAP, C1K>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
     };
     if (getenv("MG3D_SWEEP_BALANCED") && getenv("MG3D_SWEEP_BALANCED")[0] == '1') {
         /* experiment: equal shares of the linearised (tile column, plane) space, one block per CU, no lock-step */

@@ -161,7 +161,7 @@ __device__ __forceinline__ void st_stream(double *p, double2 o)
 #ifndef MG3D_KERNEL_ATTR
 #define MG3D_KERNEL_ATTR
 #endif
-template <int S, int RES, int RJ, int NW, int PF, bool PRO, bool RST, int DP, int TAP>
+template <int S, int RES, int RJ, int NW, int PF, bool PRO, bool RST, int DP, int TAP, int C1K = -1>
 __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepArgs a)
 {
     using Sh = SweepShape<S, RES>;
@@ -281,7 +281,11 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
     /* start plane: HI warm-up planes, one more if needed so that the column active at
      * local step p in row rr is (p + rr) & 1 */
     int i_s = i_out0 - HI;
-    i_s -= (g.ig0 + i_s + jt0 + 1 + a.c1) & 1;
+    /* C1K >= 0: the launcher fixes the first pass's colour at compile time, which makes every plane parity inside the step
+     * a constant (the restriction's weights and its store-or-accumulate branch).  Tried for the one-launch down-leg
+     * (round 4): the specialised step spills 464 bytes where the runtime parity has none -- not used by any launcher */
+    const int c1v = C1K >= 0 ? C1K : a.c1;
+    i_s -= (g.ig0 + i_s + jt0 + 1 + c1v) & 1;
     /* the fused restriction finishes a coarse plane one fine plane after its centre, one step late */
     const int nsteps = (i_out1 - 1 + ST) - i_s + 1 + (RES == 2 ? 2 : 0);
 
@@ -348,6 +352,10 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
     const bool own_upd[2] = {pair_own && col_upd[0], pair_own && col_upd[1]};
     const bool own_both = own_upd[0] && own_upd[1], own_only0 = own_upd[0] && !col_upd[1],
                own_only1 = own_upd[1] && !col_upd[0];
+    /* (tried in round 4 for the one-wave-per-SIMD shapes: the column masks as 64-bit lane masks in scalar registers and
+     * the select as two v_cndmask_b32 by inline asm instead of the AND + compare + two selects on byte-per-lane
+     * booleans the compiler emits -- the scalar registers it takes are spilled to VGPR lanes, v_readlane / v_writelane
+     * 117 -> 327 per three steps, 4933 -> 5127 instructions: not kept) */
     const bool k_edge_tile = tk == 0 || tk == a.ntk - 1; /* only there a pair can have one updatable column */
     /* RES == 2: the coarse points this thread completes -- rows centred on its even rows, its even column */
     bool crow_ok[RJ / 2];
@@ -643,7 +651,8 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
              * reference adds the 27 products r*w in the order ti, tj, tk (mg_3d.h:980-988): planes arrive
              * in ti order, and inside a plane the nine terms below are tj-major, tk-minor. */
             const int qq = i - ST - 1, qg = g.ig0 + qq;
-            const bool odd = (qg & 1) != 0;
+            /* (ig0 + i_s + jt0 + 1 + c1) is even, jt0 has the parity of HJ, the step's that of PAR */
+            const bool odd = C1K >= 0 ? ((HJ + 1 + C1K + PAR + ST + 1) & 1) != 0 : (qg & 1) != 0;
             const double wi = odd ? 0.25 : 0.5;
             /* the one row of another wave a thread needs: CO = 0 the last row of the wave above (first coarse row), CO = 1 the
              * first row of the wave below (last coarse row).  The outermost wave reads its own: a halo row's sum, never stored */

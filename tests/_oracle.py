@@ -103,6 +103,22 @@ def run_problem(c, L, nu, cycles, mode=0, want_u=True):
     return norms, u, init.value, secs
 
 
+def exact_residual_norm(u, d, N, h):
+    """sqrt of the EXACTLY ROUNDED sum of the squared residuals of (u, d): the residual field from the oracle
+    (mg_3d.h:819-821; bit-identical to the GPU's diffs whenever u and d are), each square rounded to double as both
+    sides do, the sum in extended precision by numpy's pairwise summation (error ~ log2(n) 2^-64: nothing at the 1e-13 the
+    GPU reduction is held to).  The oracle's own return value is the reference's SEQUENTIAL sum and carries that sum's
+    rounding error (up to n 2^-53): it pins the reference's number, this pins the GPU's reduction."""
+    res = np.zeros(N ** 3)
+    lib().orc_residual(P(np.ascontiguousarray(u)), P(np.ascontiguousarray(d)), N, h, P(res))
+    sq = res * res
+    total = np.longdouble(0)
+    step = 1 << 24
+    for a in range(0, sq.size, step):  # chunked: the extended-precision copy of a 513^3 field would be 2 GB
+        total += np.sum(sq[a:a + step].astype(np.longdouble))
+    return float(np.sqrt(total))
+
+
 class EsParams(C.Structure):
     """orc_es_params (same layout as the product's mg3d_es_params); defaults = mg_3d_bkup.c:12-18"""
     _fields_ = [("length", C.c_double), ("capillary_radius", C.c_double), ("extractor_inner", C.c_double),

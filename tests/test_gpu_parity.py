@@ -23,6 +23,19 @@ def norm_rtol(N):
 
 
 NORM_RTOL = norm_rtol(33)  # levels up to 33^3: 2e-12
+# The GPU's OWN reduction (wave shuffle -> LDS -> per-block partial sums -> fold) is held to this against the exactly
+# rounded sum of the same squares (O.exact_residual_norm), whatever the size: a dropped or doubled partial sum of 1e-9
+# relative weight would pass norm_rtol(513) = 7e-9 -- it does not pass this.
+EXACT_NORM_RTOL = 1e-13
+
+
+def assert_norm_exact(s, level, got_norm):
+    """`got_norm` is the residual norm the library returned for the state now on `level`: compare with the exactly
+    rounded sum over the oracle's residual field of the downloaded (bit-identical) u and d."""
+    u, d = s.download(MG3D_U, level), s.download(MG3D_D, level)
+    want = O.exact_residual_norm(u, d, s.level_n(level), s.level_h(level))
+    assert got_norm == pytest.approx(want, rel=EXACT_NORM_RTOL), (got_norm, want)
+
 
 G = np.load(os.path.join(O.GOLDEN, "operators.npz"))
 V = np.load(os.path.join(O.GOLDEN, "vcycle.npz"))
@@ -269,6 +282,7 @@ def test_vcycle_history_and_solution_bit_exact(c, L, nu):
         assert s.get_initial_residual() == pytest.approx(want_init, rel=rt)
         got = np.array([s.lin_solve() for _ in range(cycles)])
         u = s.download(MG3D_U, L - 1)
+        assert_norm_exact(s, L - 1, got[-1])  # the GPU reduction itself, to 1e-13 (the bound above is the reference's)
     np.testing.assert_allclose(got, want_norms, rtol=rt, atol=0)
     assert np.array_equal(u, want_u)
     key = f"{c}_{L}_{nu}"
@@ -593,6 +607,7 @@ def test_full_size_513_bit_exact_against_oracle(monkeypatch):
         assert {kn: n for (lvl, kn), (n, _) in s.kernel_times().items() if lvl == 6}.get("sweep4+norm") == 2
         s.timing_enable(0)
         u = s.download(MG3D_U, 6)
+        assert_norm_exact(s, 6, got[-1])  # 133 M squares: the GPU's tree sum against the exactly rounded one, 1e-13
     assert np.array_equal(u, want_u)
     np.testing.assert_allclose(got, want_norms, rtol=norm_rtol(513))
     O.lib().orc_set_threads(1)
