@@ -131,15 +131,15 @@ def test_single_cycle_calls_run_the_next_down_leg_ahead_and_other_calls_swap_it_
 
 
 def test_leg_launches_are_taken_and_counted(monkeypatch):
-    """K cycles of one call: K up-leg and K down-leg launches on the top level and one norm-only launch (the last cycle's),
-    nothing else there; off by default."""
+    """K cycles of one call: K up-leg and K down-leg launches on the top level, one norm-only launch (the last cycle's) and
+    the first cycle's face injection, nothing else there; off by default."""
     _legs(monkeypatch, True)
     with M.Solver(9, 5, 2) as s:
         s.setup_test_problem()
         s.timing_enable(1)
         s.vcycles(5)
         kt = {kn: n for (lvl, kn), (n, _) in s.kernel_times().items() if lvl == 4}
-    assert kt == {"leg_up": 5, "leg_down": 5, "residual": 1}, kt
+    assert kt == {"leg_up": 5, "leg_down": 5, "residual": 1, "restrict": 1}, kt  # (restrict: the face injection, first cycle only)
     monkeypatch.delenv("MG3D_LEGS")
     with M.Solver(9, 5, 2) as s:
         s.setup_test_problem()
