@@ -109,7 +109,13 @@ int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm);
  * first red pre-smoothing pass of a cycle that follows another one is the identity, so a cycle's last two post-smoothing
  * passes, its norm and the next cycle's pre-smoothing passes run as one launch.  mg3d_vcycles does so inside a call;
  * mg3d_vcycle(finest level) ends ahead of itself, and every other entry point first restores the finished cycle's own u
- * (observable results are those of separate cycles, bit for bit; MG3D_NO_CARRY=1 switches it off). */
+ * (every grid value -- u, d, r of every level -- is that of separate cycles, bit for bit; the returned norm sums the same
+ * squares in another grouping of per-block partial sums and agrees to the summation tolerance, <= 1e-13 relative against
+ * the exactly rounded sum: tests/test_gpu_parity.py; MG3D_NO_CARRY=1 switches it off).
+ * MG3D_LEGS=1 (opt-in, round 4): one launch per leg on the finest level instead -- prolongation + four passes, three
+ * passes + residual + restriction -- with the norm's two halves taken from the launches on either side of it; behind a
+ * single mg3d_vcycle the next cycle's down-leg runs ahead into spare buffers and is swapped back when anything else is
+ * asked (csrc/mg3d_ctx.hip, mg3d_can_legs).  Same bits. */
 int mg3d_vcycle(mg3d_ctx *ctx, int level, double *norm);
 int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms);
 

@@ -78,6 +78,7 @@ int mg3d_fail(int code, const char *fmt, ...);
 int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out = 0);
 bool mg3d_can_carry(const mg3d_ctx *ctx, int q);
 bool mg3d_can_legs(const mg3d_ctx *ctx, int q);
-void mg3d_drop_carry(mg3d_ctx *ctx); /* carried state -> the finished cycle's own u; a no-op otherwise */
+/* carried state -> the finished cycle's own u; a no-op (MG3D_OK) otherwise.  An error leaves the carried state in place. */
+int mg3d_drop_carry(mg3d_ctx *ctx);
 
 #endif

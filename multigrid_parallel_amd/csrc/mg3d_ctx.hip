@@ -229,7 +229,7 @@ static mg3d_ctx *ctx_new(int L, int iters)
  * two passes (black, red) from alt -- one launch, paid only when somebody wants to see or change the state between two
  * cycles.  Every entry point that reads or writes level data, or changes what a cycle is, calls this first; only
  * mg3d_vcycle(s) continue from the carried state. */
-void mg3d_drop_carry(mg3d_ctx *ctx)
+int mg3d_drop_carry(mg3d_ctx *ctx)
 {
     if (ctx && ctx->legs_state != 0) {
         /* one launch per leg: behind mg3d_vcycle the next cycle's down-leg has run ahead into the alt buffers; the finished
@@ -244,13 +244,19 @@ void mg3d_drop_carry(mg3d_ctx *ctx)
         ctx->legs_state = 0;
     }
     if (!ctx || !ctx->carried)
-        return;
+        return MG3D_OK;
     Level &l = ctx->lv[ctx->L - 1];
-    ctx->carried = false;
     const int np = k_sweep(l.g, l.alt, l.f[MG3D_D], l.f[MG3D_U], nullptr, nullptr, MG3D_MAX_PARTIALS, l.h, 2, 0, false,
                            ctx->stream);
+    /* a failure leaves the context where it was -- u three passes into the next cycle, `carried` still set: the caller
+     * returns the error instead of going on with (and handing out) a state nobody asked for; a later call tries again */
     if (np < 0)
-        (void)fail(MG3D_ERR_STATE, "carried cycle: the two passes that finish it could not be launched");
+        return fail(MG3D_ERR_STATE, "carried cycle: the two passes that finish it could not be launched");
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return fail(MG3D_ERR_HIP, "carried cycle: the two passes that finish it: %s", hipGetErrorString(e));
+    ctx->carried = false;
+    return MG3D_OK;
 }
 
 void mg3d_ctx_touched(mg3d_ctx *ctx, int field, int level, bool raw_pointer)
@@ -345,7 +351,7 @@ extern "C" double mg3d_ctx_level_h(const mg3d_ctx *ctx, int level)
 }
 extern "C" int mg3d_ctx_set_keep_residual(mg3d_ctx *ctx, int keep)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     if (!ctx)
         return fail(MG3D_ERR_ARG, "mg3d_ctx_set_keep_residual: NULL context");
     ctx->keep_r = keep != 0;
@@ -354,7 +360,7 @@ extern "C" int mg3d_ctx_set_keep_residual(mg3d_ctx *ctx, int keep)
 
 extern "C" int mg3d_ctx_set_smooth_iters(mg3d_ctx *ctx, int iters)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     if (!ctx || iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_ctx_set_smooth_iters: bad arguments");
     ctx->iters = iters;
@@ -500,7 +506,7 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
 
 extern "C" int mg3d_ctx_set_lu(mg3d_ctx *ctx, const double *LU)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     if (!ctx || !LU)
         return fail(MG3D_ERR_ARG, "mg3d_ctx_set_lu: NULL argument");
     const int N0 = ctx->lv[0].g.N;
@@ -516,7 +522,7 @@ extern "C" int mg3d_ctx_set_lu(mg3d_ctx *ctx, const double *LU)
 
 extern "C" int mg3d_ctx_build_coarse(mg3d_ctx *ctx, double h_coarse)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     if (!ctx)
         return fail(MG3D_ERR_ARG, "mg3d_ctx_build_coarse: NULL context");
     const int N0 = ctx->lv[0].g.N;
@@ -543,7 +549,7 @@ static int check_field_level(const mg3d_ctx *ctx, int field, int level, const ch
 
 extern "C" int mg3d_upload(mg3d_ctx *ctx, int field, int level, const double *host)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     CHK(check_field_level(ctx, field, level, "mg3d_upload"));
     if (!host)
         return fail(MG3D_ERR_ARG, "mg3d_upload: NULL host pointer");
@@ -558,7 +564,7 @@ extern "C" int mg3d_upload(mg3d_ctx *ctx, int field, int level, const double *ho
 
 extern "C" int mg3d_download(mg3d_ctx *ctx, int field, int level, double *host)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     CHK(check_field_level(ctx, field, level, "mg3d_download"));
     if (!host)
         return fail(MG3D_ERR_ARG, "mg3d_download: NULL host pointer");
@@ -572,7 +578,7 @@ extern "C" int mg3d_download(mg3d_ctx *ctx, int field, int level, double *host)
 
 extern "C" int mg3d_zero(mg3d_ctx *ctx, int field, int level)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     CHK(check_field_level(ctx, field, level, "mg3d_zero"));
     const Level &l = ctx->lv[level];
     HIPCHK(hipMemsetAsync(l.f[field], 0, l.elems * sizeof(double), ctx->stream));
@@ -592,7 +598,7 @@ extern "C" int mg3d_sync(mg3d_ctx *ctx)
 extern "C" int mg3d_device_view(mg3d_ctx *ctx, int field, int level, void **dev_ptr, int *pitch_doubles,
                                 long *plane_doubles)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     CHK(check_field_level(ctx, field, level, "mg3d_device_view"));
     const Level &l = ctx->lv[level];
     mg3d_ctx_touched(ctx, field, level, true);
@@ -752,7 +758,7 @@ static int enqueue_residual(mg3d_ctx *ctx, int level, int store, int slot)
 
 extern "C" int mg3d_smooth(mg3d_ctx *ctx, int level, int post, int iters)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     CHK(check_field_level(ctx, 0, level, "mg3d_smooth"));
     if (iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_smooth: negative iteration count");
@@ -762,7 +768,7 @@ extern "C" int mg3d_smooth(mg3d_ctx *ctx, int level, int post, int iters)
 
 extern "C" int mg3d_residual(mg3d_ctx *ctx, int level, int store, double *norm)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     CHK(check_field_level(ctx, 0, level, "mg3d_residual"));
     CHK(enqueue_residual(ctx, level, store, 0));
     CHK(launch_ok("mg3d_residual"));
@@ -771,7 +777,7 @@ extern "C" int mg3d_residual(mg3d_ctx *ctx, int level, int store, double *norm)
 
 extern "C" int mg3d_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters, int store, double *norm)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     CHK(check_field_level(ctx, 0, level, "mg3d_smooth_residual"));
     if (iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_smooth_residual: negative iteration count");
@@ -782,7 +788,7 @@ extern "C" int mg3d_smooth_residual(mg3d_ctx *ctx, int level, int post, int iter
 
 extern "C" int mg3d_smooth_restrict(mg3d_ctx *ctx, int level, int iters)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     CHK(check_field_level(ctx, 0, level, "mg3d_smooth_restrict"));
     if (level < 1 || iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_smooth_restrict: bad level/iteration count");
@@ -795,7 +801,7 @@ extern "C" int mg3d_smooth_restrict(mg3d_ctx *ctx, int level, int iters)
 
 extern "C" int mg3d_restrict(mg3d_ctx *ctx, int level)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     CHK(check_field_level(ctx, 0, level, "mg3d_restrict"));
     if (level < 1)
         return fail(MG3D_ERR_ARG, "mg3d_restrict: level 0 has no coarser level");
@@ -806,7 +812,7 @@ extern "C" int mg3d_restrict(mg3d_ctx *ctx, int level)
 
 extern "C" int mg3d_prolong(mg3d_ctx *ctx, int level)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     CHK(check_field_level(ctx, 0, level, "mg3d_prolong"));
     if (level < 1)
         return fail(MG3D_ERR_ARG, "mg3d_prolong: level 0 has no coarser level");
@@ -817,7 +823,7 @@ extern "C" int mg3d_prolong(mg3d_ctx *ctx, int level)
 
 extern "C" int mg3d_coarse_solve(mg3d_ctx *ctx)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     if (!ctx)
         return fail(MG3D_ERR_ARG, "mg3d_coarse_solve: NULL context");
     if (!ctx->have_lu)
@@ -830,7 +836,7 @@ extern "C" int mg3d_coarse_solve(mg3d_ctx *ctx)
 
 extern "C" int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     CHK(check_field_level(ctx, field, level, "mg3d_l2norm"));
     k_sumsq(ctx->lv[level].g, ctx->lv[level].f[field], ctx->partials, ctx->sumsq, ctx->stream);
     CHK(launch_ok("mg3d_l2norm"));
@@ -917,7 +923,7 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out)
     const bool can_legs = mg3d_can_legs(ctx, q);
     const bool can_carry = !can_legs && mg3d_can_carry(ctx, q);
     if ((ctx->carried && !can_carry) || (ctx->legs_state != 0 && !can_legs)) /* e.g. MG3D_NO_CARRY set between two calls: finish the carried cycle, go on plainly */
-        mg3d_drop_carry(ctx);
+        CHK(mg3d_drop_carry(ctx));
     const bool carry_in = ctx->carried;
     ctx->carried = false;
     const int legs_in = ctx->legs_state;
@@ -1173,14 +1179,14 @@ extern "C" int mg3d_vcycle(mg3d_ctx *ctx, int level, double *norm)
         return MG3D_OK;
     }
     if (level != ctx->L - 1)
-        mg3d_drop_carry(ctx);
+        CHK(mg3d_drop_carry(ctx));
     /* One cycle per call is how the reference's solve loop runs (SolverLinSolve, mg_3d.h:1415-1420): the call ends with
      * the launch that also begins the NEXT cycle -- speculatively; whatever the caller does instead of another cycle
      * first puts the finished cycle's own u back (mg3d_drop_carry), and the norm returned is this cycle's either way.
      * Not once a raw pointer to u or d of the top level is out (mg3d_ctx_touched). */
     const int rc = mg3d_enqueue_vcycle(ctx, level, 0, ctx->raw_top ? 0 : 2);
     if (rc != MG3D_OK) {
-        mg3d_drop_carry(ctx);
+        (void)mg3d_drop_carry(ctx); /* the first error is the one reported */
         return rc;
     }
     return read_norm(ctx, 0, norm);
@@ -1201,10 +1207,10 @@ extern "C" int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms)
     }
     const int batch = ctx->sumsq_slots - 1;
     if (count == 0) /* (behind a single mg3d_vcycle call the first cycle continues from the carried state) */
-        mg3d_drop_carry(ctx);
+        CHK(mg3d_drop_carry(ctx));
     struct Guard { /* an error return must not leave u of the top level a few passes into a cycle nobody asked for */
         mg3d_ctx *c;
-        ~Guard() { mg3d_drop_carry(c); }
+        ~Guard() { (void)mg3d_drop_carry(c); }
     } guard{ctx};
     for (int done = 0; done < count;) {
         const int nb = (count - done < batch) ? count - done : batch;
@@ -1225,7 +1231,7 @@ extern "C" int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms)
 /* -------------------------------------------------------------------- FMG */
 extern "C" int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     CHK(check_field_level(ctx, field, level, "mg3d_fill_boundary"));
     k_fill_boundary(ctx->lv[level].g, ctx->lv[level].f[field], ctx->lv[level].h, ctx->stream);
     mg3d_ctx_touched(ctx, field, level);
@@ -1235,7 +1241,7 @@ extern "C" int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level)
 /* SolverFMGInitialize, mg_dirichlet_analytic.c:771-806 */
 extern "C" int mg3d_fmg_initialize(mg3d_ctx *ctx)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     if (!ctx)
         return fail(MG3D_ERR_ARG, "mg3d_fmg_initialize: NULL context");
     if (!ctx->have_lu)

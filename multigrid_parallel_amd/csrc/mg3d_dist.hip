@@ -217,6 +217,17 @@ struct mg3d_dist {
     std::vector<Plan> plans_carry; /* a cycle that ends ahead into the next one (policy bit 1) */
     const std::vector<Plan> *cur;  /* the plan of the cycle being enqueued */
     bool carried;                  /* u of the top level holds three pre-smoothing passes of the next cycle */
+    /* a call failed after a cycle of it had carried: u of the top level is three passes into a cycle nobody finished and
+     * nothing here can put the finished cycle's own u back (the single-domain path has mg3d_drop_carry; on slabs that
+     * would be two passes over the owned planes AND a full halo exchange -- on a handle whose transport may just have
+     * failed).  Every later call that reads or continues from u fails loudly until u of the top level is uploaded again. */
+    bool poisoned;
+    /* carried cycles on or off, decided ONCE for a multi-rank RCCL job (mg3d_dist_create: the ranks agree by an
+     * all-reduce) -- the two plans differ in the HALO_U_NEXT phase (3 planes against H - 1), and ranks that read
+     * MG3D_NO_CARRY / MG3D_CARRY_MIN differently per cycle would post sends and receives of different sizes: a hang or
+     * corrupted halos without a diagnostic.  Loopback and single-rank handles keep reading the environment per cycle
+     * (the tests toggle it). */
+    bool carry_fixed, carry_on;
     int n_carried;                 /* cycles that ended that way (mg3d_dist_carried_cycles) */
     int phase;  /* next phase of the cycle being enqueued */
     int policy; /* bit 0: coarse levels on rank 0 only (MG3D_COARSE_GATHER=1) */
@@ -291,6 +302,9 @@ __global__ void sum_in_order_kernel(const double *__restrict__ parts, int n, dou
         *out = t;
     }
 }
+
+static bool dist_carry_policy(mg3d_dist *D);
+static int dist_refuse_poisoned(const mg3d_dist *D, const char *who);
 
 extern "C" int mg3d_comm_unique_id(void *out128)
 {
@@ -530,7 +544,27 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
                          D->policy | 2); /* same arguments as above: cannot fail where that did not */
     D->cur = &D->plans;
     D->carried = false;
+    D->poisoned = false;
     D->n_carried = 0;
+    D->carry_fixed = false;
+    D->carry_on = false;
+    if (D->have_comm && nranks > 1) {
+        /* every rank must pick the same plan variant: all-reduce MIN of "carried cycles are on here" */
+        int mine = dist_carry_policy(D) ? 1 : 0, *dflag = nullptr;
+        bool ok = hipMalloc(&dflag, sizeof(int)) == hipSuccess &&
+                  hipMemcpyAsync(dflag, &mine, sizeof(int), hipMemcpyHostToDevice, D->stream) == hipSuccess &&
+                  ncclAllReduce(dflag, dflag, 1, ncclInt, ncclMin, D->comm, D->stream) == ncclSuccess &&
+                  hipMemcpyAsync(&mine, dflag, sizeof(int), hipMemcpyDeviceToHost, D->stream) == hipSuccess &&
+                  hipStreamSynchronize(D->stream) == hipSuccess;
+        if (dflag)
+            (void)hipFree(dflag);
+        if (!ok) {
+            mg3d_dist_destroy(D);
+            return fail(MG3D_ERR_HIP, "mg3d_dist_create: the ranks could not agree on the cycle schedule (all-reduce failed)");
+        }
+        D->carry_fixed = true;
+        D->carry_on = mine != 0;
+    }
     *out = D;
     return MG3D_OK;
 }
@@ -589,6 +623,7 @@ extern "C" int mg3d_dist_set_keep_residual(mg3d_dist *D, int keep)
 {
     if (!D)
         return fail(MG3D_ERR_ARG, "mg3d_dist_set_keep_residual: NULL");
+    CHK(dist_refuse_poisoned(D, "mg3d_dist_set_keep_residual"));
     for (auto &R : D->rs)
         R.coarse->keep_r = keep != 0;
     return MG3D_OK;
@@ -623,6 +658,8 @@ extern "C" int mg3d_dist_upload(mg3d_dist *D, int field, int level, const double
 {
     if (!D || !host)
         return fail(MG3D_ERR_ARG, "mg3d_dist_upload: NULL");
+    if (field == MG3D_U && level == D->L - 1)
+        D->poisoned = false; /* u of the finest level, halos included, is replaced: nothing of the failed call is left */
     for (auto &R : D->rs) {
         double *p;
         Geom g;
@@ -642,6 +679,7 @@ extern "C" int mg3d_dist_download(mg3d_dist *D, int field, int level, double *ho
 {
     if (!D || !host)
         return fail(MG3D_ERR_ARG, "mg3d_dist_download: NULL");
+    CHK(dist_refuse_poisoned(D, "mg3d_dist_download"));
     for (auto &R : D->rs) {
         double *p;
         Geom g;
@@ -859,7 +897,7 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
 }
 
 /* carried cycles on slabs (csrc/mg3d_ctx.hip has the argument): same conditions as the single-domain path */
-static bool dist_can_carry(mg3d_dist *D)
+static bool dist_carry_policy(mg3d_dist *D) /* what the environment says, for this level geometry */
 {
     const char *e = getenv("MG3D_NO_CARRY");
     if (e && e[0] == '1')
@@ -867,8 +905,23 @@ static bool dist_can_carry(mg3d_dist *D)
     const char *m = getenv("MG3D_CARRY_MIN");
     const int n_min = m ? atoi(m) : 130;
     const Geom &g = SL(D, D->rs[0], D->L - 1).lv.g;
-    return D->nu == 2 && !D->rs[0].coarse->keep_r && g.N >= n_min && g.N > 65 && (g.nj & 1) != 0 &&
-           dist_split_up_leg(D, 1, 1);
+    return g.N >= n_min;
+}
+
+static bool dist_can_carry(mg3d_dist *D)
+{
+    if (!(D->carry_fixed ? D->carry_on : dist_carry_policy(D)))
+        return false;
+    const Geom &g = SL(D, D->rs[0], D->L - 1).lv.g;
+    return D->nu == 2 && !D->rs[0].coarse->keep_r && g.N > 65 && (g.nj & 1) != 0 && dist_split_up_leg(D, 1, 1);
+}
+
+static int dist_refuse_poisoned(const mg3d_dist *D, const char *who)
+{
+    if (D->poisoned)
+        return fail(MG3D_ERR_STATE, "%s: an earlier mg3d_dist_vcycles call failed after one of its cycles had run ahead into the "
+                                    "next: u of the finest level is mid-cycle; upload it again first", who);
+    return MG3D_OK;
 }
 
 static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false)
@@ -1011,15 +1064,27 @@ extern "C" int mg3d_dist_vcycles(mg3d_dist *D, int count, double *norms)
 {
     if (!D || count < 0)
         return fail(MG3D_ERR_ARG, "mg3d_dist_vcycles: bad arguments");
+    CHK(dist_refuse_poisoned(D, "mg3d_dist_vcycles"));
+    const int carried_before = D->n_carried;
+    /* any error return below: if a cycle of this call has carried, u of the finest level may be three passes into a cycle
+     * that was never finished (also across a batch boundary, where D->carried is still set) -- see `poisoned` */
+    struct Guard {
+        mg3d_dist *d;
+        int before;
+        bool ok;
+        ~Guard()
+        {
+            if (!ok && (d->carried || d->n_carried != before))
+                d->poisoned = true;
+            if (!ok)
+                d->carried = false;
+        }
+    } guard{D, carried_before, false};
     for (int done = 0; done < count;) {
         const int nb = (count - done < D->norm_slots) ? count - done : D->norm_slots;
         for (int c = 0; c < nb; c++) {
             /* every cycle but the last of a call ends ahead into the next one (a call never ends in the carried state) */
-            const int rc = dist_enqueue_vcycle(D, c, done + c + 1 < count);
-            if (rc != MG3D_OK) {
-                D->carried = false;
-                return rc;
-            }
+            CHK(dist_enqueue_vcycle(D, c, done + c + 1 < count));
         }
         CHK(dist_finish(D));
         HIPCHK(hipMemcpyAsync(D->h_norms, D->d_norms, nb * sizeof(double), hipMemcpyDeviceToHost, D->stream));
@@ -1040,5 +1105,6 @@ extern "C" int mg3d_dist_vcycles(mg3d_dist *D, int count, double *norms)
                 norms[done + c] = sqrt(D->h_norms[c]);
         done += nb;
     }
+    guard.ok = true;
     return MG3D_OK;
 }

@@ -168,7 +168,7 @@ static int launch_ok_es(const char *who)
 
 extern "C" int mg3d_es_setup(mg3d_ctx *ctx, const mg3d_es_params *p)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     if (!ctx || !p || !(p->length > 0.))
         return fail(MG3D_ERR_ARG, "mg3d_es_setup: bad arguments");
     if (p->length != ctx->length)
@@ -204,7 +204,7 @@ extern "C" int mg3d_es_setup(mg3d_ctx *ctx, const mg3d_es_params *p)
 
 extern "C" int mg3d_es_smooth(mg3d_ctx *ctx, int level, int post, int iters)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     if (!ctx || !ctx->have_es || level < 0 || level >= ctx->L || iters < 0)
         return fail(MG3D_ERR_ARG, "mg3d_es_smooth: bad arguments (mg3d_es_setup first)");
     es_smooth(ctx, level, post, iters);
@@ -247,7 +247,7 @@ static int es_vcycle(mg3d_ctx *ctx, int q, int slot)
 
 extern "C" int mg3d_es_vcycles(mg3d_ctx *ctx, int count, double *norms)
 {
-    mg3d_drop_carry(ctx);
+    CHK(mg3d_drop_carry(ctx));
     if (!ctx || count < 0 || !ctx->have_es)
         return fail(MG3D_ERR_ARG, "mg3d_es_vcycles: bad arguments (mg3d_es_setup first)");
     if (ctx->L < 2)

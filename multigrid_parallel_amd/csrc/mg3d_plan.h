@@ -163,20 +163,35 @@ static int plan_run(const std::vector<Plan> &plans, int ph, bool loopback, ncclC
     if (pl.begin[(size_t)ph] == pl.begin[(size_t)ph + 1])
         return MG3D_OK;
     PLAN_NCCLCHK(ncclGroupStart());
-    for (int i = pl.begin[(size_t)ph]; i < pl.begin[(size_t)ph + 1]; i++) {
+    /* a failure between ncclGroupStart and ncclGroupEnd must not leave the communicator inside an open group -- every later
+     * call on it (the asynchronous-error check, teardown) would be queued and never issued: the process would hang
+     * instead of reporting.  The first error is kept, the group is closed (its own result ignored), then it is returned. */
+    ncclResult_t first = ncclSuccess;
+    const char *what = "";
+    auto in_group = [&](ncclResult_t r, const char *call) {
+        if (r != ncclSuccess && first == ncclSuccess) {
+            first = r;
+            what = call;
+        }
+    };
+    for (int i = pl.begin[(size_t)ph]; i < pl.begin[(size_t)ph + 1] && first == ncclSuccess; i++) {
         const mg3d_xfer &e = pl.e[(size_t)i];
         const size_t cnt = (size_t)e.count * e.plane_elems;
         if (e.op == MG3D_XOP_ALLGATHER) {
-            PLAN_NCCLCHK(ncclAllGather(sumsq(0), gather, cnt, ncclDouble, comm, s));
+            in_group(ncclAllGather(sumsq(0), gather, cnt, ncclDouble, comm, s), "ncclAllGather");
             continue;
         }
         T *p = base(0, e) + e.plane_elems * e.offset;
         if (e.op == MG3D_XOP_SEND)
-            PLAN_NCCLCHK(ncclSend(p, cnt, dt, e.peer, comm, s));
+            in_group(ncclSend(p, cnt, dt, e.peer, comm, s), "ncclSend");
         else if (e.op == MG3D_XOP_RECV)
-            PLAN_NCCLCHK(ncclRecv(p, cnt, dt, e.peer, comm, s));
+            in_group(ncclRecv(p, cnt, dt, e.peer, comm, s), "ncclRecv");
         else
-            PLAN_NCCLCHK(ncclBroadcast(p, p, cnt, dt, e.peer, comm, s));
+            in_group(ncclBroadcast(p, p, cnt, dt, e.peer, comm, s), "ncclBroadcast");
+    }
+    if (first != ncclSuccess) {
+        (void)ncclGroupEnd();
+        return mg3d_fail(MG3D_ERR_HIP, "exchange plan, phase %d: %s: %s", ph, what, ncclGetErrorString(first));
     }
     PLAN_NCCLCHK(ncclGroupEnd());
     return MG3D_OK;
