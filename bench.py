@@ -458,20 +458,27 @@ def main():
     kt = solver.kernel_times()
     # the same K cycles with every cycle run on its own (MG3D_NO_CARRY=1: no launch shared between consecutive cycles,
     # csrc/mg3d_ctx.hip "carried cycles"), no timers: reported beside `value`; both schedules give the same bits
-    plain = None
-    if world == 1 and not os.environ.get("MG3D_NO_CARRY"):
-        os.environ["MG3D_NO_CARRY"] = "1"
-        try:
-            solver.vcycles(2)
-            barrier(solver)
-            t1 = time.perf_counter()
-            solver.vcycles(args.steps)
-            barrier(solver)
-            el1 = time.perf_counter() - t1
-            plain = {"value": args.steps / el1, "ms_per_step": el1 / args.steps * 1e3,
-                     "what": "MG3D_NO_CARRY=1: four launches per cycle on the finest level, none shared between cycles"}
-        finally:
-            del os.environ["MG3D_NO_CARRY"]
+    plain = legs = None
+    if world == 1:
+        def timed_with(key, value, what):
+            old = solver.get_option(key)
+            solver.set_option(key, value)  # the options API (mg3d_ctx_set_option): no environment on any launch path
+            try:
+                solver.vcycles(3)
+                barrier(solver)
+                t1 = time.perf_counter()
+                solver.vcycles(args.steps)
+                barrier(solver)
+                el1 = time.perf_counter() - t1
+                return {"value": args.steps / el1, "ms_per_step": el1 / args.steps * 1e3, "what": what}
+            finally:
+                solver.set_option(key, old)
+        if solver.get_option("carry") and not solver.get_option("legs"):
+            plain = timed_with("carry", 0, "option carry = 0: four launches per cycle on the finest level, none shared between cycles")
+        if not solver.get_option("legs"):
+            legs = timed_with("legs", 1, "option legs = 1 (opt-in, round 4): ONE launch per leg on the finest level -- prolongation + "
+                                         "four passes, three passes + residual + restriction, the norm's halves taken from either "
+                                         "side; 6.75 GB compulsory per cycle instead of 10.0, at one wave per SIMD (issue-bound)")
     fin = L - 1
     n_f = N ** 3
 
@@ -494,6 +501,11 @@ def main():
                         "(its first red pass is the identity)", 3 * n_f * w, 6 * n_f * w + 2 * n_f * w),
         "sweep1+restrict": ("last pre-smoothing pass + residual + full-weighting restriction, r never stored",
                             3 * n_f * w + n_c * w, 1.5 * n_f * w + 3 * n_f * w + (n_f + n_c) * w),
+        # one launch per leg (option legs)
+        "leg_down": ("3 (behind another cycle; else 4) pre-smoothing passes + residual + full-weighting restriction in ONE launch",
+                     3 * n_f * w + n_c * w, 4.5 * n_f * w + 3 * n_f * w + (n_f + n_c) * w),
+        "leg_up": ("prolongation + 4 post-smoothing passes (+ the red half of the norm) in ONE launch",
+                   3 * n_f * w + n_c * w, (n_c + 2 * n_f) * w + 6 * n_f * w),
         "colour_pass": ("one colour pass", 3 * n_f * w, 1.5 * n_f * w),
         "prolong": ("prolongation", 2 * n_f * w + n_c * w, (n_c + 2 * n_f) * w),
         "restrict": ("face injection of the restriction", 0, 0),
@@ -607,8 +619,10 @@ def main():
             "first_norm": float(norms[0]), "last_norm": float(norms[-1]), "initial_rhs_norm": init,
             "cycles_to_1e-8": to_tol,  # test_mg_3d.c stopping rule; the reference needs 16 at 513^3
             # consecutive cycles of the timed call share a launch on the finest level (identical results)
-            "schedule": "carried cycles" if any(r["kernel"] == "sweep4+norm" for r in launches_tab) else "plain",
+            "schedule": "one launch per leg" if any(r["kernel"] == "leg_up" for r in launches_tab) else
+                        "carried cycles" if any(r["kernel"] == "sweep4+norm" for r in launches_tab) else "plain",
             "plain_schedule": plain,
+            "legs_schedule": legs,
             "roofline": roof,
         }
         if args.breakdown:

@@ -126,6 +126,34 @@ int mg3d_fmg_initialize(mg3d_ctx *ctx);
 /* setupBoundaryConditions (mg_3d.h:1147-1239) on a device-resident field */
 int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level);
 
+/* Launch and schedule policy of a context, by key.  Defaults, then the environment as an override read ONCE when the
+ * context is created, afterwards only this call: nothing on a launch path reads the environment, two contexts of one
+ * process may differ.  Grid values never depend on any of them (tests/test_gpu_parity.py, tests/test_gpu_legs.py compare).
+ *   key             default  environment at creation   meaning
+ *   carry           1        MG3D_NO_CARRY=1 -> 0      consecutive V(2,2) cycles share a launch on the finest level
+ *   carry_min       130      MG3D_CARRY_MIN            ... from this many points per side
+ *   legs            0        MG3D_LEGS                 one launch per leg on the finest level instead (see above)
+ *   legs_min        130      MG3D_LEGS_MIN             ... from this many points per side
+ *   tiny            1        MG3D_NO_TINY=1 -> 0       the level above the coarsest one in one workgroup
+ *   tiny_cycle      1        MG3D_NO_TINY_CYCLE=1 -> 0 ... together with the direct solve in one launch
+ *   lu_reduced      1        MG3D_LU_REDUCED           install the factor without its identity rows (read per factor)
+ *   fuse_rst2       -1       MG3D_FUSE_RST2            2 passes + residual + restriction in one launch: -1 from 130 points
+ *                                                      per side, 0 never, 1 always
+ *   small_max       129      MG3D_SMALL_MAX            largest level side that runs the two-rows-per-thread shapes
+ *   fuse_leg_max    0        MG3D_FUSE_LEG_MAX         largest level side whose legs run as one (two-row) launch each
+ *   fuse_up_max     0        MG3D_FUSE_UP_MAX          largest level side whose up-leg folds the prolongation into 4 passes
+ *   sweep_tune      -1       MG3D_SWEEP_TUNE           first-use measurement of chunk lengths: -1 on unless the process
+ *                                                      drives a multi-rank RCCL job, 0 off, 1 on
+ *   sweep_tune_log  0        MG3D_SWEEP_TUNE_LOG       print the measured choices
+ *   sweep_ci        0        MG3D_SWEEP_CI             > 0: planes per chunk of every fused sweep launch (measurement)
+ *   sweep_rj/nw/pf  0        MG3D_SWEEP_CFG="rj,nw,pf" another compiled tile shape (unknown ones fall back to the default)
+ * mg3d_option_name(i) enumerates the keys (NULL past the end).  mg3d_dist_set_option forwards to every local rank (carry /
+ * carry_min of a multi-rank job are agreed at creation and refuse to change); mg3d32_set_option knows "pairs", "fuse",
+ * "carry" (MG3D_F32_NO_PAIRS / _NO_FUSE / _NO_CARRY at creation). */
+int mg3d_ctx_set_option(mg3d_ctx *ctx, const char *key, int value);
+int mg3d_ctx_get_option(const mg3d_ctx *ctx, const char *key, int *value);
+const char *mg3d_option_name(int index);
+
 /* per-stage timers (timing_info.h:6-47), filled from hipEvent pairs recorded in-stream (no stall).
  * on: 0 = off, 1 = every level, 2 = finest level only, 3 = the kernel timers of the finest level only (no stage
  * timers: a third of the marker packets, what bench.py's roofline object needs), 4 + k = as 3 on every (k+2)-th full
@@ -195,6 +223,7 @@ int mg3d_dist_halo(const mg3d_dist *d);        /* halo planes per side */
 int mg3d_dist_carried_cycles(const mg3d_dist *d); /* cycles since creation that ended ahead into the next one ("carried cycles") */
 int mg3d_dist_build_coarse(mg3d_dist *d, double h_coarse);
 int mg3d_dist_set_keep_residual(mg3d_dist *d, int keep); /* as mg3d_ctx_set_keep_residual */
+int mg3d_dist_set_option(mg3d_dist *d, const char *key, int value); /* as mg3d_ctx_set_option, for every local rank */
 int mg3d_dist_upload(mg3d_dist *d, int field, int level, const double *host_full);
 int mg3d_dist_download(mg3d_dist *d, int field, int level, double *host_full);
 int mg3d_dist_vcycles(mg3d_dist *d, int count, double *norms);
@@ -293,6 +322,7 @@ typedef struct mg3d32_ctx mg3d32_ctx;
 int mg3d32_create(int coarse_pts, int num_levels, int smooth_iters, double omega, double grid_length,
                   mg3d32_ctx **out);
 int mg3d32_destroy(mg3d32_ctx *ctx);
+int mg3d32_set_option(mg3d32_ctx *ctx, const char *key, int value); /* "pairs", "fuse", "carry": see mg3d_ctx_set_option */
 int mg3d32_level_n(const mg3d32_ctx *ctx, int level);
 int mg3d32_upload(mg3d32_ctx *ctx, int field, int level, const float *host);
 int mg3d32_download(mg3d32_ctx *ctx, int field, int level, float *host);

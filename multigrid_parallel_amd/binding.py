@@ -74,6 +74,11 @@ SIGNATURES = {
     "mg3d_dist_halo": (C.c_int, [C.c_void_p]),
     "mg3d_dist_carried_cycles": (C.c_int, [C.c_void_p]),
     "mg3d_dist_set_keep_residual": (C.c_int, [C.c_void_p, C.c_int]),
+    "mg3d_dist_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "mg3d_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "mg3d_ctx_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "mg3d_option_name": (C.c_char_p, [C.c_int]),
+    "mg3d32_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "mg3d_dist_build_coarse": (C.c_int, [C.c_void_p, C.c_double]),
     "mg3d_dist_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
     "mg3d_dist_download": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
@@ -227,6 +232,23 @@ class Solver:
 
     def set_keep_residual(self, keep=True):
         check(self.L.mg3d_ctx_set_keep_residual(self._h, int(keep)))
+
+    def set_option(self, key, value):
+        """mg3d_ctx_set_option: launch / schedule policy by key (include/mg3d.h has the table)."""
+        check(self.L.mg3d_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int(0)
+        check(self.L.mg3d_ctx_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def options(self):
+        out, i = {}, 0
+        while self.L.mg3d_option_name(i):
+            k = self.L.mg3d_option_name(i).decode()
+            out[k] = self.get_option(k)
+            i += 1
+        return out
 
     # -- geometry
     def level_n(self, level):
@@ -435,6 +457,9 @@ class DistSolver:
     def set_keep_residual(self, keep=True):
         check(self.L.mg3d_dist_set_keep_residual(self._h, int(keep)))
 
+    def set_option(self, key, value):
+        check(self.L.mg3d_dist_set_option(self._h, key.encode(), int(value)))
+
     def setup_test_problem(self):
         """test_mg_3d.c:11-29 on the full grid; every rank takes its slab."""
         check(self.L.mg3d_dist_build_coarse(self._h, self.h * (1 << (self.num_levels - 1))))
@@ -507,6 +532,10 @@ class Solver32:
 
     def __exit__(self, *exc):
         self.close()
+
+    def set_option(self, key, value):
+        """mg3d32_set_option: "pairs", "fuse", "carry" (1 on, 0 off)."""
+        check(self.L.mg3d32_set_option(self._h, key.encode(), int(value)))
 
     def level_n(self, level):
         return self.L.mg3d32_level_n(self._h, level)

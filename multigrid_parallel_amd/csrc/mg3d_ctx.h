@@ -52,6 +52,7 @@ struct mg3d_ctx {
      * level's next right-hand side sits in that level's alt buffer; the finished cycle's own u is in the top level's alt */
     int legs_state, legs_slot, legs_npa;
     bool raw_top; /* a raw device pointer to u or d of the top level was handed out (mg3d_device_view) */
+    mg3d_options opt; /* launch / schedule policy (mg3d_options_init at creation, mg3d_ctx_set_option afterwards) */
     bool fused; /* fused sweep kernel (default) or one launch per colour pass (MG3D_NO_FUSE=1) */
     int timing; /* 0 off, 1 every level, 2 finest level only, 3 finest level's kernel timers only, 4 + k: 3 on every (k+2)-th cycle */
     int timing_phase; /* cycles since the last sampled one (timing >= 4) */

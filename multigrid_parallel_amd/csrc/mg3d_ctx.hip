@@ -187,6 +187,70 @@ extern "C" int mg3d_ctx_destroy(mg3d_ctx *ctx)
     return MG3D_OK;
 }
 
+/* ------------------------------------------------------------------ options
+ * One table: key, environment override (read once per context creation), how the environment value maps, default. */
+struct OptionRow {
+    const char *key, *env;
+    int mode; /* 0: the value is the integer; 1: "1" means 0 (a NO_ switch), anything else 1; 2: "rj,nw,pf" */
+    int dflt;
+};
+static const OptionRow kOptionTable[MG3D_OPT_COUNT] = {
+    {"carry", "MG3D_NO_CARRY", 1, 1},
+    {"carry_min", "MG3D_CARRY_MIN", 0, 130},
+    {"legs", "MG3D_LEGS", 0, 0},
+    {"legs_min", "MG3D_LEGS_MIN", 0, 130},
+    {"tiny", "MG3D_NO_TINY", 1, 1},
+    {"tiny_cycle", "MG3D_NO_TINY_CYCLE", 1, 1},
+    {"lu_reduced", "MG3D_LU_REDUCED", 0, 1},
+    {"fuse_rst2", "MG3D_FUSE_RST2", 0, -1},
+    {"small_max", "MG3D_SMALL_MAX", 0, 129},
+    {"fuse_leg_max", "MG3D_FUSE_LEG_MAX", 0, 0},
+    {"fuse_up_max", "MG3D_FUSE_UP_MAX", 0, 0},
+    {"sweep_tune", "MG3D_SWEEP_TUNE", 0, -1},
+    {"sweep_tune_log", "MG3D_SWEEP_TUNE_LOG", 0, 0},
+    {"sweep_ci", "MG3D_SWEEP_CI", 0, 0},
+    {"sweep_rj", "MG3D_SWEEP_CFG", 2, 0},
+    {"sweep_nw", nullptr, 0, 0},
+    {"sweep_pf", nullptr, 0, 0},
+};
+
+void mg3d_options_init(mg3d_options *o)
+{
+    for (int i = 0; i < MG3D_OPT_COUNT; i++) {
+        const OptionRow &r = kOptionTable[i];
+        o->v[i] = r.dflt;
+        const char *e = r.env ? getenv(r.env) : nullptr; /* context creation: the only place the environment is read */
+        if (!e || !e[0])
+            continue;
+        if (r.mode == 0)
+            o->v[i] = atoi(e);
+        else if (r.mode == 1)
+            o->v[i] = e[0] == '1' ? 0 : 1;
+        else {
+            int rj = 0, nw = 0, pf = 0;
+            if (sscanf(e, "%d,%d,%d", &rj, &nw, &pf) >= 2) {
+                o->v[MG3D_OPT_SWEEP_RJ] = rj;
+                o->v[MG3D_OPT_SWEEP_NW] = nw;
+                o->v[MG3D_OPT_SWEEP_PF] = pf;
+            }
+            i += 2; /* the two rows behind it were just set */
+        }
+    }
+}
+
+int mg3d_option_index(const char *key)
+{
+    if (key)
+        for (int i = 0; i < MG3D_OPT_COUNT; i++)
+            if (strcmp(key, kOptionTable[i].key) == 0)
+                return i;
+    return -1;
+}
+
+const char *mg3d_option_key(int index) { return index >= 0 && index < MG3D_OPT_COUNT ? kOptionTable[index].key : nullptr; }
+
+extern "C" const char *mg3d_option_name(int index) { return mg3d_option_key(index); }
+
 static mg3d_ctx *ctx_new(int L, int iters)
 {
     mg3d_ctx *ctx = new mg3d_ctx();
@@ -214,6 +278,7 @@ static mg3d_ctx *ctx_new(int L, int iters)
     ctx->fused = true;
     ctx->carried = false;
     ctx->legs_state = ctx->legs_slot = ctx->legs_npa = 0;
+    mg3d_options_init(&ctx->opt);
     ctx->raw_top = false;
     ctx->keep_r = false;
     if (const char *e = getenv("MG3D_KEEP_R"))
@@ -246,7 +311,7 @@ int mg3d_drop_carry(mg3d_ctx *ctx)
     if (!ctx || !ctx->carried)
         return MG3D_OK;
     Level &l = ctx->lv[ctx->L - 1];
-    const int np = k_sweep(l.g, l.alt, l.f[MG3D_D], l.f[MG3D_U], nullptr, nullptr, MG3D_MAX_PARTIALS, l.h, 2, 0, false,
+    const int np = k_sweep(ctx->opt, l.g, l.alt, l.f[MG3D_D], l.f[MG3D_U], nullptr, nullptr, MG3D_MAX_PARTIALS, l.h, 2, 0, false,
                            ctx->stream);
     /* a failure leaves the context where it was -- u three passes into the next cycle, `carried` still set: the caller
      * returns the error instead of going on with (and handing out) a state nobody asked for; a later call tries again */
@@ -355,6 +420,29 @@ extern "C" int mg3d_ctx_set_keep_residual(mg3d_ctx *ctx, int keep)
     if (!ctx)
         return fail(MG3D_ERR_ARG, "mg3d_ctx_set_keep_residual: NULL context");
     ctx->keep_r = keep != 0;
+    return MG3D_OK;
+}
+
+/* launch / schedule policy by key (the table in INTEGRATION.md): takes effect from the next call on; anything that
+ * changes what a cycle is first finishes a cycle that has run ahead */
+extern "C" int mg3d_ctx_set_option(mg3d_ctx *ctx, const char *key, int value)
+{
+    CHK(mg3d_drop_carry(ctx));
+    if (!ctx)
+        return fail(MG3D_ERR_ARG, "mg3d_ctx_set_option: NULL context");
+    const int i = mg3d_option_index(key);
+    if (i < 0)
+        return fail(MG3D_ERR_ARG, "mg3d_ctx_set_option: no option \"%s\"", key ? key : "(null)");
+    ctx->opt.v[i] = value;
+    return MG3D_OK;
+}
+
+extern "C" int mg3d_ctx_get_option(const mg3d_ctx *ctx, const char *key, int *value)
+{
+    const int i = mg3d_option_index(key);
+    if (!ctx || !value || i < 0)
+        return fail(MG3D_ERR_ARG, "mg3d_ctx_get_option: NULL argument or no option \"%s\"", key ? key : "(null)");
+    *value = ctx->opt.v[i];
     return MG3D_OK;
 }
 
@@ -471,8 +559,7 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
      * unknowns, half-band 49 instead of 81): the same values in the same order for every remaining term, i.e. the same
      * bits, in less than half the strictly sequential steps.  The solve kernel checks the right-hand side and takes
      * the full system whenever an identity row's entry is not a zero (the F-cycle start, host-pointer calls). */
-    const bool no_reduce = getenv("MG3D_LU_REDUCED") && getenv("MG3D_LU_REDUCED")[0] == '0'; /* read per factor: tests compare both */
-    if (no_reduce || !ctx->lu.stream_ch)
+    if (!ctx->opt.v[MG3D_OPT_LU_REDUCED] || !ctx->lu.stream_ch) /* (option lu_reduced, read per factor: tests compare both) */
         return MG3D_OK;
     std::vector<int> map((size_t)n, -1), rows;
     for (long long i = 0; i < n; i++) {
@@ -486,9 +573,6 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
         }
     }
     const long long ni = (long long)rows.size(), npad_in = (ni + 63) / 64 * 64;
-    if (getenv("MG3D_LU_LOG"))
-        fprintf(stderr, "mg3d lu: n %lld bw %d R %d, %lld rows are not identity rows (padded %lld of %d)\n", n, ctx->lu.bw,
-                ctx->lu.rot_r, ni, npad_in, ctx->lu.npad);
     if (ni == 0 || ni == n || 2 * npad_in > ctx->lu.npad)
         return MG3D_OK; /* nothing to gain, or the reduced vectors do not fit beside the full right-hand side in LDS */
     CHK(build_band(ctx->lu_in, ni, [&](long long a, long long b) { return LU[(long long)rows[(size_t)a] * n + rows[(size_t)b]]; }));
@@ -496,9 +580,6 @@ static int install_lu(mg3d_ctx *ctx, const double *LU, long long n, size_t work_
         free_band(ctx->lu_in);
         return MG3D_OK;
     }
-    if (getenv("MG3D_LU_LOG"))
-        fprintf(stderr, "mg3d lu: reduced factor n %d bw %d R %d stream %d\n", ctx->lu_in.n, ctx->lu_in.bw, ctx->lu_in.rot_r,
-                ctx->lu_in.stream_ch);
     HIPCHK(hipMalloc(&ctx->lu.in_map, (size_t)n * sizeof(int)));
     HIPCHK(hipMemcpy(ctx->lu.in_map, map.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
     return MG3D_OK;
@@ -632,12 +713,8 @@ static int read_norm(mg3d_ctx *ctx, int slot, double *norm)
     return MG3D_OK;
 }
 
-/* post-smoothing of 4 passes + norm as 2 + 2 passes (see enqueue_smooth_residual); MG3D_SPLIT22=0 keeps 4 + 0 */
-static bool split_up_leg(int iters, int want_res)
-{
-    static const bool off = getenv("MG3D_SPLIT22") && getenv("MG3D_SPLIT22")[0] == '0';
-    return !off && 2 * iters == 4 && want_res == 1;
-}
+/* post-smoothing of 4 passes + norm as 2 + 2 passes (see enqueue_smooth_residual) */
+static bool split_up_leg(int iters, int want_res) { return 2 * iters == 4 && want_res == 1; }
 
 /* iters x (two colour passes), optionally followed by the residual of the result.
  * Fused path: chunks of 4 (or 2) passes per launch, each launch reading u and writing the
@@ -673,22 +750,21 @@ static int enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters
             /* the residual rides on a 2-pass launch; behind 4 passes it gets its own launch (the 5-stage
              * window leaves too few registers for a tile with a useful interior: measured 1.9 ms fused
              * against 0.85 + 0.76 ms split on a 513^3 level) */
-            static const bool res4 = getenv("MG3D_FUSE_RES4") && getenv("MG3D_FUSE_RES4")[0] == '1'; /* experiment */
             /* two passes + residual + restriction (the down-leg of V(1,1), the tail of V(3,3)'s): one launch from 130
              * points per side up, two below (k_sweep_fuse_rst2) */
             /* small levels (<= MG3D_FUSE_LEG_MAX points per side): the whole down-leg -- four passes, residual,
              * restriction -- as one launch of the two-rows-per-thread shape: it wastes three quarters of its rows
              * and saves a launch where launches are paid in latency, not in bytes */
-            const bool leg4 = S == 4 && coarse != nullptr && !need_norm && want_res != 0 && l.g.N <= k_sweep_fuse_leg_max();
-            const bool res = last && want_res != 0 && (S != 4 || (res4 && coarse == nullptr) || leg4) &&
-                             !(S == 2 && coarse != nullptr && !k_sweep_fuse_rst2(l.g.N));
+            const bool leg4 = S == 4 && coarse != nullptr && !need_norm && want_res != 0 && l.g.N <= ctx->opt.v[MG3D_OPT_FUSE_LEG_MAX];
+            const bool res = last && want_res != 0 && (S != 4 || leg4) &&
+                             !(S == 2 && coarse != nullptr && !k_sweep_fuse_rst2(ctx->opt, l.g.N));
             const bool rst = res && coarse != nullptr;
             const bool with_pro = pro != nullptr && passes == 2 * iters; /* first launch only */
             int np;
             {
                 StageScope kt(ctx, level, S == 4 ? MG3D_K_SWEEP4 : S == 2 ? (res ? MG3D_K_SWEEP2_RES : MG3D_K_SWEEP2)
                                                                           : MG3D_K_RESIDUAL, true);
-                np = k_sweep(l.g, (zero_in && passes == 2 * iters) ? nullptr : l.f[MG3D_U], l.f[MG3D_D], l.alt,
+                np = k_sweep(ctx->opt, l.g, (zero_in && passes == 2 * iters) ? nullptr : l.f[MG3D_U], l.f[MG3D_D], l.alt,
                              (res && want_res == 2 && !rst) ? l.f[MG3D_R] : nullptr,
                              (res && need_norm) ? ctx->partials : nullptr,
                              MG3D_MAX_PARTIALS, l.h, S, c1, res, s, 0, -1, rst ? &coarse->g : nullptr,
@@ -730,16 +806,16 @@ static int enqueue_smooth_residual(mg3d_ctx *ctx, int level, int post, int iters
 static bool pro_fusable(const mg3d_ctx *ctx, int iters, int want_res, int level)
 {
     /* small levels: the two-rows-per-thread four-pass shape has the registers for the prolongation (k_sweep) */
-    const bool small = ctx->lv[level].g.N <= k_sweep_fuse_up_max() && 2 * iters == 4 && want_res == 0;
-    /* On a 4-pass first launch it is opt-in (MG3D_PRO_FUSE=1): bit-identical, but measured SLOWER on MI355X at 513^3 --
-     * the 4-pass sweep already uses 249 VGPRs, the prologue spills 44 dwords and the launch takes 1.48 ms against
-     * 0.85 ms (sweep) + 0.56 ms (separate prolongation kernel).  The 2-pass first launch of a split stage takes it
-     * almost for free. */
-    static const bool on = getenv("MG3D_PRO_FUSE") && getenv("MG3D_PRO_FUSE")[0] == '1';
+    const int up_max = ctx->opt.v[MG3D_OPT_FUSE_UP_MAX] > ctx->opt.v[MG3D_OPT_FUSE_LEG_MAX] ? ctx->opt.v[MG3D_OPT_FUSE_UP_MAX]
+                                                                                             : ctx->opt.v[MG3D_OPT_FUSE_LEG_MAX];
+    const bool small = ctx->lv[level].g.N <= up_max && 2 * iters == 4 && want_res == 0;
+    /* On a 4-pass first launch of a level above small_max it is bit-identical but SLOWER (the four-row shape spills; round
+     * 2 measured 1.48 ms against 0.85 + 0.56 at 513^3): only where fuse_up_max asks for it.  The 2-pass first launch of a
+     * split stage takes it almost for free. */
     if (!ctx->fused || iters < 1)
         return false;
     const bool sp = split_up_leg(iters, want_res);
-    if (!on && !sp && !small)
+    if (!sp && !small)
         return false;
     const int first = (2 * iters >= 4 && !sp) ? 4 : 2;
     const bool first_has_res = want_res != 0 && first == 2 && 2 * iters == 2;
@@ -870,26 +946,23 @@ extern "C" int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm)
  * (mg3d_drop_carry: no launch).  Same conditions as the carried cycles; MG3D_LEGS=0 / 1 switches it off / on. */
 bool mg3d_can_legs(const mg3d_ctx *ctx, int q)
 {
-    const char *e = getenv("MG3D_LEGS"); /* read per call: tests toggle it */
-    const bool on = e ? e[0] == '1' : false;
-    if (!on)
+    if (!ctx->opt.v[MG3D_OPT_LEGS])
         return false;
-    const char *m = getenv("MG3D_LEGS_MIN");
-    const int n_min = m ? atoi(m) : 130;
-    return mg3d_can_carry(ctx, q) && ctx->lv[q].g.N >= n_min;
+    const mg3d_ctx *c = ctx;
+    /* the conditions of the carried cycles, except their own switch and threshold */
+    return c->fused && !c->keep_r && !c->have_es && c->iters == 2 && q == c->L - 1 && q >= 2 && c->lv[q].g.N >= c->opt.v[MG3D_OPT_LEGS_MIN] &&
+           c->lv[q].g.N > 65 && (c->lv[q].g.nj & 1) != 0;
 }
 
 bool mg3d_can_carry(const mg3d_ctx *ctx, int q)
 {
-    const char *e = getenv("MG3D_NO_CARRY"); /* read per call: tests toggle it */
-    if (e && e[0] == '1')
+    if (!ctx->opt.v[MG3D_OPT_CARRY])
         return false;
     /* from 257^3 up: there the launch saved is bytes (257^3: +5 %, 513^3: +17 %, 1025^3: +16 % V-cycles/s); at 129^3 a
      * launch is pipeline fill and the plain schedule's lighter launches are 1 % ahead.  MG3D_CARRY_MIN=<points per side>
      * moves the threshold (the tests run 129^3 problems); never at 65^3 and below (the two launches only exist in
      * the four-rows-per-thread shapes) */
-    const char *m = getenv("MG3D_CARRY_MIN");
-    const int n_min = m ? atoi(m) : 130;
+    const int n_min = ctx->opt.v[MG3D_OPT_CARRY_MIN];
     return ctx->fused && !ctx->keep_r && !ctx->have_es && ctx->iters == 2 && q == ctx->L - 1 && q >= 2 &&
            ctx->lv[q].g.N >= n_min && ctx->lv[q].g.N > 65 && (ctx->lv[q].g.nj & 1) != 0 && split_up_leg(2, 1) &&
            pro_fusable(ctx, 2, 1, q);
@@ -914,11 +987,11 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out)
         }
     } tick{ctx, q == L - 1};
     /* level 1 below the top of the cycle, small enough for one workgroup's LDS: two launches instead of five */
-    const bool no_tiny = getenv("MG3D_NO_TINY") && getenv("MG3D_NO_TINY")[0] == '1'; /* read per cycle: tests toggle it */
+    const bool no_tiny = !ctx->opt.v[MG3D_OPT_TINY];
     const bool tiny = !no_tiny && ctx->fused && !ctx->keep_r && q >= 2 && ctx->iters >= 1 && k_tiny_fits(ctx->lv[1].g, ctx->lv[0].g);
     /* ... and the whole bottom of the cycle (level 1 down, the direct solve, level 1 up) as ONE launch when the reduced
      * factor exists (mg3d_tiny.hip, tiny_cycle_kernel); MG3D_NO_TINY_CYCLE=1 keeps the three launches (tests compare) */
-    const bool no_cyc = getenv("MG3D_NO_TINY_CYCLE") && getenv("MG3D_NO_TINY_CYCLE")[0] == '1';
+    const bool no_cyc = !ctx->opt.v[MG3D_OPT_TINY_CYCLE];
     const bool tiny_cyc = tiny && !no_cyc && k_tiny_cycle_fits(ctx->lv[1].g, ctx->lv[0].g, ctx->lu, ctx->lu_in);
     const bool can_legs = mg3d_can_legs(ctx, q);
     const bool can_carry = !can_legs && mg3d_can_carry(ctx, q);
@@ -946,7 +1019,7 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out)
                     StageScope kt(ctx, l, MG3D_K_LEG_DOWN, true);
                     /* behind another cycle: black, red, black (the first red pass is the identity) and the black half of
                      * that cycle's norm; else the four passes of :1282.  + residual + restriction (:1294 + :1310) */
-                    const int np = k_sweep_leg_down(lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, lc.g, lc.f[MG3D_D], lev.h,
+                    const int np = k_sweep_leg_down(ctx->opt, lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, lc.g, lc.f[MG3D_D], lev.h,
                                                     legs_in == 2 ? 3 : 4, legs_in == 2 ? part_b : nullptr, MG3D_MAX_PARTIALS / 2, s);
                     if (np < 0)
                         return fail(MG3D_ERR_STATE, "one launch per leg: no kernel for the down-leg");
@@ -970,7 +1043,7 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out)
             { /* the one pre-smoothing pass that is left (black) + residual + restriction (:1282 + :1294 + :1310) */
                 StageScope t(ctx, l, MG3D_ST_SMOOTH1);
                 StageScope kt(ctx, l, MG3D_K_SWEEP1_RESTRICT, true);
-                const int np = k_sweep(lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, nullptr, nullptr, MG3D_MAX_PARTIALS, lev.h,
+                const int np = k_sweep(ctx->opt, lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, nullptr, nullptr, MG3D_MAX_PARTIALS, lev.h,
                                        1, 0, true, s, 0, -1, &ctx->lv[l - 1].g, ctx->lv[l - 1].f[MG3D_D]);
                 if (np < 0)
                     return fail(MG3D_ERR_STATE, "carried cycle: no kernel for one pass + residual + restriction");
@@ -1083,7 +1156,7 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out)
                     StageScope kt(ctx, l, MG3D_K_LEG_UP, true);
                     /* prolongation + black, red, black, red (:1331 + :1341); with another cycle behind it, the red half of
                      * the norm (:1354) from the last pass's sums */
-                    npa = k_sweep_leg_up(lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, lc.g, lc.f[MG3D_U], lev.h,
+                    npa = k_sweep_leg_up(ctx->opt, lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, lc.g, lc.f[MG3D_U], lev.h,
                                          carry_out ? part_a : nullptr, MG3D_MAX_PARTIALS / 2, s);
                 }
                 if (npa < 0)
@@ -1098,7 +1171,7 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out)
                 } else if (carry_out == 2) {
                     /* mg3d_vcycle: the next cycle's down-leg now, into the alt buffers (see mg3d_can_legs) */
                     StageScope kt(ctx, l, MG3D_K_LEG_DOWN, true);
-                    const int npb = k_sweep_leg_down(lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, lc.g, lc.alt, lev.h, 3, part_b,
+                    const int npb = k_sweep_leg_down(ctx->opt, lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, lc.g, lc.alt, lev.h, 3, part_b,
                                                      MG3D_MAX_PARTIALS / 2, s);
                     if (npb < 0)
                         return fail(MG3D_ERR_STATE, "one launch per leg: no kernel for the down-leg");
@@ -1125,7 +1198,7 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out)
                 /* black, red (:1341, second half) <norm, :1354> black, red (:1282 of the next cycle, its first red pass
                  * being the identity) */
                 StageScope kt(ctx, l, MG3D_K_SWEEP4_NORM, true);
-                const int np = k_sweep_tap(lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, ctx->partials, MG3D_MAX_PARTIALS,
+                const int np = k_sweep_tap(ctx->opt, lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, ctx->partials, MG3D_MAX_PARTIALS,
                                            lev.h, 0, s);
                 if (np < 0)
                     return fail(MG3D_ERR_STATE, "carried cycle: no kernel for four passes + norm tap");

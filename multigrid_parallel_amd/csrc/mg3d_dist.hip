@@ -225,8 +225,8 @@ struct mg3d_dist {
     /* carried cycles on or off, decided ONCE for a multi-rank RCCL job (mg3d_dist_create: the ranks agree by an
      * all-reduce) -- the two plans differ in the HALO_U_NEXT phase (3 planes against H - 1), and ranks that read
      * MG3D_NO_CARRY / MG3D_CARRY_MIN differently per cycle would post sends and receives of different sizes: a hang or
-     * corrupted halos without a diagnostic.  Loopback and single-rank handles keep reading the environment per cycle
-     * (the tests toggle it). */
+     * corrupted halos without a diagnostic.  Loopback and single-rank handles follow their options (mg3d_dist_set_option)
+     * from cycle to cycle (the tests toggle them). */
     bool carry_fixed, carry_on;
     int n_carried;                 /* cycles that ended that way (mg3d_dist_carried_cycles) */
     int phase;  /* next phase of the cycle being enqueued */
@@ -619,6 +619,24 @@ extern "C" int mg3d_dist_first_level(const mg3d_dist *D) { return D ? D->ld : -1
 extern "C" int mg3d_dist_halo(const mg3d_dist *D) { return D ? D->H : -1; }
 extern "C" int mg3d_dist_carried_cycles(const mg3d_dist *D) { return D ? D->n_carried : -1; }
 
+/* launch / schedule policy by key (mg3d_ctx_set_option) for every local rank.  carry / carry_min of a multi-rank RCCL job
+ * are fixed when the handle is created (the ranks agree there) and refuse to change. */
+extern "C" int mg3d_dist_set_option(mg3d_dist *D, const char *key, int value)
+{
+    if (!D)
+        return fail(MG3D_ERR_ARG, "mg3d_dist_set_option: NULL");
+    const int i = mg3d_option_index(key);
+    if (i < 0)
+        return fail(MG3D_ERR_ARG, "mg3d_dist_set_option: no option \"%s\"", key ? key : "(null)");
+    if (D->carry_fixed && (i == MG3D_OPT_CARRY || i == MG3D_OPT_CARRY_MIN))
+        return fail(MG3D_ERR_STATE, "mg3d_dist_set_option: %s is agreed between the ranks at creation", key);
+    if (D->carried)
+        return fail(MG3D_ERR_STATE, "mg3d_dist_set_option: inside a carried cycle");
+    for (auto &R : D->rs)
+        CHK(mg3d_ctx_set_option(R.coarse, key, value));
+    return MG3D_OK;
+}
+
 extern "C" int mg3d_dist_set_keep_residual(mg3d_dist *D, int keep)
 {
     if (!D)
@@ -802,8 +820,7 @@ struct RestrictTarget { /* where a rank's restricted residual goes: coarse geome
  * the norm into the second (same policy and reasons as the single-domain path, csrc/mg3d_ctx.hip) */
 static bool dist_split_up_leg(const mg3d_dist *D, int post, int want_res)
 {
-    static const bool off = getenv("MG3D_SPLIT22") && getenv("MG3D_SPLIT22")[0] == '0';
-    return !off && post && 2 * D->nu == 4 && want_res == 1;
+    return post && 2 * D->nu == 4 && want_res == 1;
 }
 
 struct ProlongSource { /* per local rank: the coarse correction a split up-leg folds into its first launch */
@@ -828,7 +845,7 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
         const bool last = passes - S == 0;
         /* two passes + residual + restriction: one launch from 130 points per side up, two below (k_sweep_fuse_rst2) */
         const bool res = last && want_res != 0 && S != 4 &&
-                         !(S == 2 && tgt != nullptr && !k_sweep_fuse_rst2(SL(D, D->rs[0], l).lv.g.N));
+                         !(S == 2 && tgt != nullptr && !k_sweep_fuse_rst2(D->rs[0].coarse->opt, SL(D, D->rs[0], l).lv.g.N));
         if (S == 0 && refresh_u) { /* u is final; the pure residual launch below reads owned +-1 only */
             CHK(start_u_exchange(D, MG3D_XK_HALO_U_NEXT, l));
             refresh_u = false;
@@ -859,14 +876,14 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
             if (tap && last) {
                 /* output: the owned planes only -- the four passes use up the halo planes the first launch has left, and
                  * the next launch (one pass + residual + restriction) gets three fresh ones by exchange first */
-                const int np = k_sweep_tap(lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt, cx->partials, MG3D_MAX_PARTIALS, lv.h, c1, s,
+                const int np = k_sweep_tap(cx->opt, lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt, cx->partials, MG3D_MAX_PARTIALS, lv.h, c1, s,
                                            sl.own_lo, sl.own_hi, sl.own_lo, sl.own_hi);
                 if (np < 0)
                     return fail(MG3D_ERR_STATE, "slab sweep: no kernel for four passes + norm tap on level %d", l);
                 k_fold(cx->partials, np, cx->sumsq, s);
                 continue;
             }
-            const int np = k_sweep(lv.g, (zero_in && first) ? nullptr : lv.f[MG3D_U], lv.f[MG3D_D], lv.alt,
+            const int np = k_sweep(cx->opt, lv.g, (zero_in && first) ? nullptr : lv.f[MG3D_U], lv.f[MG3D_D], lv.alt,
                                    (res && want_res == 2 && !rst) ? lv.f[MG3D_R] : nullptr,
                                    (res && want_res == 1) ? cx->partials : nullptr, /* the pre-smoothing norm is dropped (:1294) */
                                    MG3D_MAX_PARTIALS, lv.h, S, c1, res, s, sl.own_lo, sl.own_hi,
@@ -897,15 +914,11 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
 }
 
 /* carried cycles on slabs (csrc/mg3d_ctx.hip has the argument): same conditions as the single-domain path */
-static bool dist_carry_policy(mg3d_dist *D) /* what the environment says, for this level geometry */
+static bool dist_carry_policy(mg3d_dist *D) /* what the options say (carry, carry_min), for this level geometry */
 {
-    const char *e = getenv("MG3D_NO_CARRY");
-    if (e && e[0] == '1')
-        return false;
-    const char *m = getenv("MG3D_CARRY_MIN");
-    const int n_min = m ? atoi(m) : 130;
+    const mg3d_options &o = D->rs[0].coarse->opt;
     const Geom &g = SL(D, D->rs[0], D->L - 1).lv.g;
-    return g.N >= n_min;
+    return o.v[MG3D_OPT_CARRY] != 0 && g.N >= o.v[MG3D_OPT_CARRY_MIN];
 }
 
 static bool dist_can_carry(mg3d_dist *D)
@@ -977,7 +990,7 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false)
             for (size_t ri = 0; ri < D->rs.size(); ri++) {
                 SlabLevel &sl = SL(D, D->rs[ri], l);
                 Level &lv = sl.lv;
-                const int np = k_sweep(lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt, nullptr, nullptr, MG3D_MAX_PARTIALS, lv.h, 1, 0,
+                const int np = k_sweep(D->rs[ri].coarse->opt, lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt, nullptr, nullptr, MG3D_MAX_PARTIALS, lv.h, 1, 0,
                                        true, s, sl.own_lo, sl.own_hi, tgt[ri].gc, tgt[ri].dc, tgt[ri].lo, tgt[ri].hi, nullptr,
                                        nullptr, sl.own_lo, sl.own_hi);
                 if (np < 0)

@@ -813,6 +813,7 @@ int mg3d32_create_slabs(int coarse_pts, int num_levels, int smooth_iters, double
     ctx->omega = (float)omega;
     ctx->no_pairs = getenv("MG3D_F32_NO_PAIRS") && getenv("MG3D_F32_NO_PAIRS")[0] == '1';
     ctx->no_fuse = getenv("MG3D_F32_NO_FUSE") && getenv("MG3D_F32_NO_FUSE")[0] == '1';
+    ctx->no_carry = getenv("MG3D_F32_NO_CARRY") && getenv("MG3D_F32_NO_CARRY")[0] == '1'; /* (creation: the only reads) */
     ctx->coarse64 = nullptr;
     ctx->partials = ctx->sumsq = ctx->h_sumsq = nullptr;
     ctx->stream = nullptr;
@@ -891,6 +892,23 @@ int mg3d32_create_slabs(int coarse_pts, int num_levels, int smooth_iters, double
     C32(hipStreamSynchronize(ctx->stream));
 #undef C32
     *out = ctx;
+    return MG3D_OK;
+}
+
+/* launch policy by key: "pairs" (two sweeps per launch), "fuse" (prolongation / norm / restriction folded into the
+ * sweeps' launches), "carry" (a cycle's norm tapped from the next cycle's first launch); 1 on (default), 0 off */
+extern "C" int mg3d32_set_option(mg3d32_ctx *ctx, const char *key, int value)
+{
+    if (!ctx || !key)
+        return fail(MG3D_ERR_ARG, "mg3d32_set_option: NULL argument");
+    if (strcmp(key, "pairs") == 0)
+        ctx->no_pairs = value == 0;
+    else if (strcmp(key, "fuse") == 0)
+        ctx->no_fuse = value == 0;
+    else if (strcmp(key, "carry") == 0)
+        ctx->no_carry = value == 0;
+    else
+        return fail(MG3D_ERR_ARG, "mg3d32_set_option: no option \"%s\"", key);
     return MG3D_OK;
 }
 
@@ -976,8 +994,6 @@ bool e32_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot, bool prolo
             const bool with_tap = tap_slot >= 0 && it == 0 && !with_norm && !with_pro;
             const int py = (l.g.nj + (with_norm ? J2N_OUT_ROWS : J2_OUT_ROWS) - 1) / (with_norm ? J2N_OUT_ROWS : J2_OUT_ROWS);
             int ch = 128;
-            if (const char *e = getenv("MG3D_F32_CH")) /* tuning knob: planes per i-chunk of the paired sweep */
-                ch = atoi(e) > 0 ? atoi(e) : ch;
             while (ch > 8 && (long long)px * py * ((l.g.ni + ch - 1) / ch) < 1024)
                 ch /= 2;
             while ((with_norm || with_tap) && (long long)px * py * ((l.g.ni + ch - 1) / ch) > MG3D_MAX_PARTIALS)
@@ -1061,8 +1077,6 @@ void e32_residual_restrict(mg3d32_ctx *ctx, int level, int c_lo, int c_hi)
     if (i_hi > i_lo) {
         const int nc = i_hi - i_lo;
         int cch = 64; /* coarse planes per block */
-        if (const char *e = getenv("MG3D_F32_CCH"))
-            cch = atoi(e) > 0 ? atoi(e) : cch;
         while (cch > 4 && (long long)px * py * ((nc + cch - 1) / cch) < 1024)
             cch /= 2;
         hipLaunchKernelGGL(residual_restrict32_kernel, dim3(px, py, (nc + cch - 1) / cch), dim3(64, J2_ROWS, 1), 0,
@@ -1113,11 +1127,10 @@ static int launch_ok32(const char *who)
  * cycle n (:1354) is a tap on cycle n+1's first launch (jacobi32x2_kernel<.,.,TAP>) instead of a third stage on cycle n's
  * last one -- whose two-stage form (prolongation + two sweeps) keeps two more rows of its tile and one plane less in
  * flight.  Nothing about u changes; only the norm arrives one launch later, inside the same mg3d32_vcycles call (the
- * last cycle of a batch forms its own).  V(2,2) with the paired, fused launches only; MG3D_F32_NO_CARRY=1 switches it off. */
+ * last cycle of a batch forms its own).  V(2,2) with the paired, fused launches only; mg3d32_set_option("carry", 0) (or MG3D_F32_NO_CARRY=1 when the context is created) switches it off. */
 bool e32_can_carry(const mg3d32_ctx *ctx)
 {
-    const char *e = getenv("MG3D_F32_NO_CARRY");
-    if (e && e[0] == '1')
+    if (ctx->no_carry)
         return false;
     return ctx->iters == 2 && !ctx->no_pairs && !ctx->no_fuse && ctx->L >= 2 && ctx->lv[ctx->L - 1].g.N >= 33;
 }

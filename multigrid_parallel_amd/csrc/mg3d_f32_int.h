@@ -30,7 +30,7 @@ struct mg3d32_ctx {
     int sumsq_slots;
     /* MG3D_F32_NO_PAIRS=1 / MG3D_F32_NO_FUSE=1, read when the context is created: one launch per sweep / per
      * operator instead of the paired and fused kernels (same bits; tests/test_gpu_f32.py) */
-    bool no_pairs, no_fuse;
+    bool no_pairs, no_fuse, no_carry; /* launch policy: the environment at creation, mg3d32_set_option afterwards */
 };
 
 /* a context whose levels >= first_slab are i-slabs: owned global planes [glo[l], ghi[l]) plus `halo` planes on every

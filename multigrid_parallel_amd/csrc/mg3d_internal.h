@@ -48,6 +48,37 @@ struct LuBand {
 
 #define MG3D_MAX_PARTIALS 32768
 
+/* Launch and schedule policy of ONE context: defaults, then the environment as an override read once when the context
+ * is created (mg3d_options_init), afterwards only mg3d_ctx_set_option / mg3d_dist_set_option / mg3d32_set_option.
+ * Nothing on a launch path reads the environment; two contexts of one process may differ.  Keys and environment names:
+ * kOptionTable in mg3d_ctx.hip, the table in INTEGRATION.md. */
+enum {
+    MG3D_OPT_CARRY = 0,    /* consecutive V(2,2) cycles share a launch on the finest level ("carried cycles") */
+    MG3D_OPT_CARRY_MIN,    /* ... from this many points per side (130) */
+    MG3D_OPT_LEGS,         /* one launch per leg on the finest level instead (round 4; 0) */
+    MG3D_OPT_LEGS_MIN,     /* ... from this many points per side (130) */
+    MG3D_OPT_TINY,         /* the level above the coarsest one in one workgroup */
+    MG3D_OPT_TINY_CYCLE,   /* ... together with the direct solve in ONE launch */
+    MG3D_OPT_LU_REDUCED,   /* install the factor without its identity rows beside the full one */
+    MG3D_OPT_FUSE_RST2,    /* two passes + residual + restriction as one launch: -1 from 130 points per side, 0 never, 1 always */
+    MG3D_OPT_SMALL_MAX,    /* largest level side that runs the two-rows-per-thread shapes (129) */
+    MG3D_OPT_FUSE_LEG_MAX, /* largest level side whose legs run as one (two-row) launch each (0) */
+    MG3D_OPT_FUSE_UP_MAX,  /* largest level side whose up-leg folds the prolongation into a four-pass launch (0) */
+    MG3D_OPT_SWEEP_TUNE,   /* first-use measurement of chunk lengths: -1 on unless a multi-rank job, 0 off, 1 on */
+    MG3D_OPT_SWEEP_TUNE_LOG,
+    MG3D_OPT_SWEEP_CI,     /* > 0: planes per chunk of every fused sweep launch (measurement only) */
+    MG3D_OPT_SWEEP_RJ,     /* > 0: another compiled tile shape (rows per thread, waves, planes in flight); unknown ones */
+    MG3D_OPT_SWEEP_NW,     /*      fall back to the default */
+    MG3D_OPT_SWEEP_PF,
+    MG3D_OPT_COUNT
+};
+struct mg3d_options {
+    int v[MG3D_OPT_COUNT];
+};
+void mg3d_options_init(mg3d_options *o);          /* defaults + environment */
+int mg3d_option_index(const char *key);           /* -1: no such key */
+const char *mg3d_option_key(int index);           /* NULL past the end */
+
 /* launchers (mg3d_kernels.hip); all asynchronous on `s` */
 void k_smooth_color(const Geom &g, double *v, const double *d, double hSq, int color, hipStream_t s);
 /* writes partials (one per block) then reduces them, in a fixed order, into *sumsq_out */
@@ -69,12 +100,9 @@ void k_fold2(const double *pa, int na, const double *pb, int nb, double *out, hi
  * vout (vout != vin; ignored when S == 0), then optionally the residual of the result: r (may be NULL)
  * receives it on the interior, partials (may be NULL) one sum of diff^2 per block.  Returns the number
  * of partials written (>= 0) or -1 when the (S, residual) shape has no instantiation. */
-void k_sweep_set_tune_default(int on); /* first-use chunk measurement on / off unless MG3D_SWEEP_TUNE says otherwise */
-int k_sweep_small_max(); /* MG3D_SMALL_MAX: largest level side that runs the two-rows-per-thread shapes (default 129) */
-int k_sweep_fuse_leg_max(); /* MG3D_FUSE_LEG_MAX: largest level side whose legs run as one launch each (default 65) */
-int k_sweep_fuse_up_max(); /* MG3D_FUSE_UP_MAX: largest level side whose up-leg is prolongation + four passes in ONE launch */
-bool k_sweep_fuse_rst2(int N); /* two passes + residual + restriction as ONE launch on a level of N points per side (default: from 130; MG3D_FUSE_RST2=0/1) */
-int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
+void k_sweep_set_tune_default(int on); /* first-use chunk measurement on / off where the option says -1 */
+bool k_sweep_fuse_rst2(const mg3d_options &o, int N); /* two passes + residual + restriction as ONE launch on a level of N points per side */
+int k_sweep(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
             int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo = 0,
             int acc_hi = -1 /* local planes entering the norm; default all */,
             const Geom *gc = nullptr, double *dc = nullptr /* non-NULL: also restrict the residual into the
@@ -87,17 +115,17 @@ int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, dou
 /* FOUR colour passes starting with colour c1 and, into partials, the residual norm of the state after the SECOND one
  * (the launch that ends one V-cycle -- its last two post-smoothing passes and its norm -- and begins the next: mg3d_ctx.hip,
  * "carried cycles").  Returns the number of partials written or -1. */
-int k_sweep_tap(const Geom &g, const double *vin, const double *d, double *vout, double *partials, int max_partials,
+int k_sweep_tap(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, double *partials, int max_partials,
                 double h, int c1, hipStream_t s, int acc_lo = 0, int acc_hi = -1, int i_lo = -1, int i_hi = -1);
 /* One launch per leg of a V(2,2) cycle on a level (mg3d_sweep.hip, "one launch per leg").  down: S = 4 colour passes red
  * first, or S = 3 black first (behind another cycle), + residual + full-weighting restriction into the interior of dc;
  * partials (S = 3 only): sum of diff^2 of the INCOMING state over the colour the first pass updates.  up: the input is
  * vin + P(ec), four passes black first; partials: sum of diff^2 of the RESULT over the colour the last pass updated.
  * Return value as k_sweep. */
-int k_sweep_leg_down(const Geom &g, const double *vin, const double *d, double *vout, const Geom &gc, double *dc, double h, int S,
+int k_sweep_leg_down(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, const Geom &gc, double *dc, double h, int S,
                      double *partials, int max_partials, hipStream_t s, int acc_lo = 0, int acc_hi = -1, int ic_lo = -1,
                      int ic_hi = -1, int i_lo = -1, int i_hi = -1);
-int k_sweep_leg_up(const Geom &g, const double *vin, const double *d, double *vout, const Geom &gce, const double *ec, double h,
+int k_sweep_leg_up(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, const Geom &gce, const double *ec, double h,
                    double *partials, int max_partials, hipStream_t s, int acc_lo = 0, int acc_hi = -1, int i_lo = -1,
                    int i_hi = -1);
 /* mg3d_tiny.hip: the level above the coarsest one in one workgroup (LDS-resident), when it fits (N <= 17) */

@@ -471,8 +471,7 @@ void k_prolong(const Geom &gc, const double *ec, const Geom &gf, double *ef, hip
     const int hi = if_hi >= 0 ? if_hi : ((gf.ig0 + gf.ni == gf.N) ? gf.ni : gf.ni - 1);
     if (hi <= lo)
         return;
-    static const bool simple = getenv("MG3D_SIMPLE_PROLONG") && getenv("MG3D_SIMPLE_PROLONG")[0] == '1';
-    if (!simple && gf.nk == 2 * gc.nk - 1 && gf.nj == 2 * gc.nj - 1) {
+    if (gf.nk == 2 * gc.nk - 1 && gf.nj == 2 * gc.nj - 1) {
         const int gx = ((gf.nk + 1) / 2 + 63) / 64, gy = ((gf.nj + 1) / 2 + 3) / 4;
         int chunk = 64; /* a few hundred to a few thousand blocks, like the sweep */
         while (chunk > 4 && (long long)gx * gy * ((hi - lo + chunk - 1) / chunk) < 2048)
@@ -592,8 +591,7 @@ static size_t lu_stream_lds(int npad, int R) { return sizeof(double) * (2 * (siz
 
 int mg3d_lu_stream_chunk(int n, int R)
 {
-    static const bool off = getenv("MG3D_LU_STREAM") && getenv("MG3D_LU_STREAM")[0] == '0';
-    if (off || R < 1 || R > 2)
+    if (R < 1 || R > 2)
         return 0;
     int dev = 0, max_lds = 0;
     if (hipGetDevice(&dev) != hipSuccess ||

@@ -34,8 +34,8 @@
  *
  * Work distribution: lock-step chunks -- block -> (tile column, i-chunk), tile fastest, so all tile columns of a chunk
  * march through the same planes at the same time and find their neighbours' halo rows in L2 / the Infinity Cache
- * (launch_sweep picks the chunk length).  MG3D_SWEEP_BALANCED=1 keeps the experiment it replaced: one block per CU and
- * equal shares of the linearised (tile column, plane) space, 1.3-1.5x slower for want of that sharing.
+ * (launch_sweep picks the chunk length).  The experiment it replaced -- one block per CU and equal shares of the linearised
+ * (tile column, plane) space -- was 1.3-1.5x slower for want of that sharing (rounds 1-3 kept it behind a switch).
  * Scalar unit: every per-row / per-plane test is wave-uniform (the wave index goes through readfirstlane); they are
  * joined with `&` and selects rather than short-circuits wherever the register budget allows, because a branch per
  * row and stage (78 a step) cost the four-pass launch 9 % at 513^3 and 20 % on the levels below 129^3.
@@ -61,7 +61,7 @@
 /* the first-use measurement of chunk lengths blocks the host (hipEventSynchronize) in the middle of an enqueue: fine for
  * one process and its own stream, off by default once a process drives a real multi-rank RCCL communicator -- there every
  * rank's stream also waits for its neighbours, and a host that stops enqueueing is one more thing that has never run on
- * more than one GPU here (MG3D_SWEEP_TUNE=1 / 0 overrides either way) */
+ * more than one GPU here (option sweep_tune = 1 / 0 overrides either way) */
 static std::atomic<int> g_sweep_tune_default{1};
 void k_sweep_set_tune_default(int on) { g_sweep_tune_default.store(on); }
 
@@ -90,7 +90,7 @@ static int device_cus() /* of the CURRENT device (a process may drive several: m
 }
 
 template <int S, int RES, int RJ, int NW, int PF, bool PRO = false, bool RST = true, int DP = 0, int TAP = -1, int C1K = -1>
-static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
+static int launch_sweep(const mg3d_options &o, SweepArgs &a, int max_partials, hipStream_t s)
 {
     using Sh = SweepShape<S, RES>;
     constexpr int VJ = NW * RJ - 2 * Sh::HJ;
@@ -102,9 +102,6 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
     auto tiles_for = [&](int vk) { return g.nk <= 2 * WAVE ? 1 : (g.nk - 2 * WAVE + vk - 1) / vk + 1; };
     const int vk_tight = 2 * WAVE - 2 * Sh::HK, vk_line = 2 * WAVE - 16;
     a.vk = (Sh::HK <= 8 && tiles_for(vk_line) <= tiles_for(vk_tight)) ? vk_line : vk_tight;
-    if (const char *e = getenv("MG3D_SWEEP_VK"))
-        if (atoi(e) == 1)
-            a.vk = vk_tight;
     a.hk = (2 * WAVE - a.vk) / 2;
     a.ntk = tiles_for(a.vk);
     /* i-chunks, lock-step: block -> (tile column, chunk), tile fastest, so that all tile columns of a chunk march
@@ -161,38 +158,26 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
                 tail_ci = x;
         }
     }
-    const char *te = getenv("MG3D_SWEEP_TAIL"); /* 0: never, 1: whenever it is shorter; unset: four passes at 4 turns */
-    const int tail_mode = te ? atoi(te) : 2;
     a.CI = best_ci;
-    if (tail_ci && (tail_mode == 1 || (tail_mode == 2 && S >= 4 && (RES == 0 || RES == 3) && ((int)T + (ncu % (int)T) - 1) / (ncu % (int)T) >= 4)))
+    /* (the tail chunk is the model's choice for the four-pass shapes at four turns -- the size it was found on -- and a
+     * candidate of the measurement below everywhere else) */
+    if (tail_ci && S >= 4 && (RES == 0 || RES == 3) && ((int)T + (ncu % (int)T) - 1) / (ncu % (int)T) >= 4)
         a.CI = tail_ci;
     bool forced = false;
-    char ci_shape[32]; /* MG3D_SWEEP_CI: every shape; MG3D_SWEEP_CI_<S><RES>[P]: one shape (e.g. _02 residual + restriction) */
-    snprintf(ci_shape, sizeof ci_shape, "MG3D_SWEEP_CI_%d%d%s", S, RES, PRO ? "P" : "");
-    for (const char *name : {(const char *)ci_shape, "MG3D_SWEEP_CI"})
-        if (const char *e = getenv(name))
-            if (atoi(e) > 0 && !forced) {
-                a.CI = atoi(e) < nout ? atoi(e) : nout;
-                forced = true;
-            }
-    a.snap = 0;
-    {
-        /* MG3D_SWEEP_REV: bit 0 the restricting launches, bit 1 the smoothing launches, bit 2 the residual-norm ones */
-        static const int rev_env = getenv("MG3D_SWEEP_REV") ? atoi(getenv("MG3D_SWEEP_REV")) : 0;
-        a.rev = ((rev_env & 1) && RES == 2) || ((rev_env & 2) && RES == 0) || ((rev_env & 4) && RES == 1) ? 1 : 0;
+    if (o.v[MG3D_OPT_SWEEP_CI] > 0) { /* a fixed chunk length (measurement only) */
+        a.CI = o.v[MG3D_OPT_SWEEP_CI] < nout ? o.v[MG3D_OPT_SWEEP_CI] : nout;
+        forced = true;
     }
     long long nb = 0;
     /* XCD grouping: the blocks of one XCD group (blockIdx % 8) take a contiguous run of tile columns, so that
      * neighbouring tile columns mostly share an L2 (a tenth to a quarter fewer bytes from the fabric).  One round of
      * blocks: renumber the whole grid (1); several rounds: inside every chunk's layer (2) -- renumbering the whole
      * grid would scatter the first round over all chunks and break the lock-step. */
-    const char *xcd_env = getenv("MG3D_XCD"); /* 0 off, 1 whole grid (one round), 2 per chunk layer, 3: 1 or 2 by rounds */
-    const bool xcd_forced = xcd_env && atoi(xcd_env) != 3;
     auto set_ci = [&](int ci) {
         a.CI = ci;
         nb = T * ((nout + ci - 1) / ci);
         /* (measured in isolation, grouping 0 sometimes wins by 2 %; inside the cycle it then loses 5 %: not tuned) */
-        a.xcd_remap = xcd_forced ? atoi(xcd_env) : nb < 64 ? 0 : nb <= ncu ? 1 : 2;
+        a.xcd_remap = nb < 64 ? 0 : nb <= ncu ? 1 : 2;
     };
     auto launch = [&]() {
         static_assert(C1K < 0 || !PRO || C1K == 0, "PRO launches are post-smoothers");
@@ -200,26 +185,12 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
             return;
         hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO, RST, DP, TAP, C1K>), dim3((unsigned)nb), dim3(NW * WAVE), 0, s, a);
     };
-    if (getenv("MG3D_SWEEP_BALANCED") && getenv("MG3D_SWEEP_BALANCED")[0] == '1') {
-        /* experiment: equal shares of the linearised (tile column, plane) space, one block per CU, no lock-step */
-        a.CI = 0;
-        nb = ncu;
-        if ((long long)T * nout / nb < 4)
-            nb = (long long)T * nout / 4 > 0 ? (long long)T * nout / 4 : 1;
-        a.snap = ((long long)T * nout / nb >= 4 * ovh) ? ovh : 0;
-        a.xcd_remap = nb < 64 ? 0 : 1;
-        if (a.partials && nb > max_partials)
-            return -1;
-        launch();
-        return (int)nb;
-    }
     /* Measured choice.  The model above ranks chunk lengths by steps; what a step costs depends on how many CUs stream
      * at once and on how well the chunks keep in lock-step, which it does not know.  The first launch of a shape on a
      * level geometry therefore times the model's best few candidates (the launch is idempotent: it reads u, d, writes
      * the other buffer; every chunking gives the same bits) and the fastest is remembered for the process.
-     * MG3D_SWEEP_TUNE=0 keeps the model's choice. */
-    const char *tune_env = getenv("MG3D_SWEEP_TUNE");
-    const bool tune_on = tune_env ? tune_env[0] != '0' : g_sweep_tune_default.load() != 0;
+     * Option sweep_tune = 0 keeps the model's choice. */
+    const bool tune_on = o.v[MG3D_OPT_SWEEP_TUNE] >= 0 ? o.v[MG3D_OPT_SWEEP_TUNE] != 0 : g_sweep_tune_default.load() != 0;
     /* not for the launches that form the norm: its value depends (in the last bits) on how the points are grouped
      * into per-block partial sums, and a timing-dependent choice would make it differ from run to run */
     if (!forced && tune_on && !a.partials && T * nout >= 1024) {
@@ -281,7 +252,7 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
                 (void)hipEventDestroy(e1);
             }
             it = tuned.emplace(key, pick).first;
-            if (getenv("MG3D_SWEEP_TUNE_LOG"))
+            if (o.v[MG3D_OPT_SWEEP_TUNE_LOG])
                 fprintf(stderr, "mg3d sweep<%d,%d,%d,%d,%d,%d> %dx%dx%d planes [%d,%d): %zu candidates, chunk %d (model %d)\n",
                         S, RES, RJ, NW, PF, (int)PRO, g.ni, g.nj, g.nk, a.i_lo, a.i_hi, cand.size(), pick, model_ci);
         }
@@ -296,52 +267,49 @@ static int launch_sweep(SweepArgs &a, int max_partials, hipStream_t s)
 }
 
 /* tile shape per (S, residual): rows per thread RJ, waves NW, prefetch depth PF.  The defaults are the
- * measured best on MI355X; MG3D_SWEEP_CFG="rj,nw,pf" selects another compiled shape. */
+ * measured best on MI355X; the options sweep_rj / sweep_nw / sweep_pf select another compiled shape. */
 struct SweepCfg {
     int rj, nw, pf;
 };
 
-static SweepCfg env_cfg(SweepCfg dflt)
+static SweepCfg opt_cfg(const mg3d_options &o, SweepCfg dflt)
 {
-    if (const char *e = getenv("MG3D_SWEEP_CFG")) {
-        SweepCfg c = dflt;
-        if (sscanf(e, "%d,%d,%d", &c.rj, &c.nw, &c.pf) >= 2)
-            return c;
-    }
+    if (o.v[MG3D_OPT_SWEEP_RJ] > 0 && o.v[MG3D_OPT_SWEEP_NW] > 0)
+        return SweepCfg{o.v[MG3D_OPT_SWEEP_RJ], o.v[MG3D_OPT_SWEEP_NW], o.v[MG3D_OPT_SWEEP_PF] > 0 ? o.v[MG3D_OPT_SWEEP_PF] : dflt.pf};
     return dflt;
 }
 
-/* the first shape listed is the default; an MG3D_SWEEP_CFG that names no compiled shape falls back to it */
+/* the first shape listed is the default; a request that names no compiled shape falls back to it */
 #define TRY(S_, RES_, RJ_, NW_, PF_)                                              \
     if (c.rj == RJ_ && c.nw == NW_ && c.pf == PF_)                                \
-        return launch_sweep<S_, RES_, RJ_, NW_, PF_>(a, max_partials, s);
-#define DFLT(S_, RES_, RJ_, NW_, PF_) return launch_sweep<S_, RES_, RJ_, NW_, PF_>(a, max_partials, s);
+        return launch_sweep<S_, RES_, RJ_, NW_, PF_>(o, a, max_partials, s);
+#define DFLT(S_, RES_, RJ_, NW_, PF_) return launch_sweep<S_, RES_, RJ_, NW_, PF_>(o, a, max_partials, s);
 
-template <int S, int RES> static int dispatch(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s);
+template <int S, int RES> static int dispatch(const mg3d_options &o, SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s);
 
-template <> int dispatch<4, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<4, 1>(const mg3d_options &o, SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(4, 1, 6, 4, 1) TRY(4, 1, 6, 4, 2) TRY(4, 1, 4, 4, 2) TRY(4, 1, 4, 8, 1) TRY(4, 1, 2, 8, 2)
     DFLT(4, 1, 6, 4, 2)
 }
-template <> int dispatch<4, 0>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<4, 0>(const mg3d_options &o, SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(4, 0, 8, 4, 1) TRY(4, 0, 6, 4, 2) TRY(4, 0, 6, 4, 3) TRY(4, 0, 4, 8, 1) TRY(4, 0, 4, 8, 2)
     TRY(4, 0, 2, 8, 2) TRY(4, 0, 2, 8, 4) TRY(4, 0, 2, 16, 1)
     DFLT(4, 0, 4, 8, 1)
 }
-template <> int dispatch<2, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<2, 1>(const mg3d_options &o, SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(2, 1, 4, 8, 1) TRY(2, 1, 8, 4, 2) TRY(2, 1, 6, 4, 2) TRY(2, 1, 2, 16, 1) TRY(2, 1, 6, 8, 1)
     DFLT(2, 1, 4, 8, 1)
 }
-template <> int dispatch<2, 0>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<2, 0>(const mg3d_options &o, SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(2, 0, 6, 8, 1) TRY(2, 0, 8, 4, 2) TRY(2, 0, 4, 8, 1) TRY(2, 0, 4, 8, 2) TRY(2, 0, 4, 8, 3)
     TRY(2, 0, 2, 8, 4) TRY(2, 0, 2, 16, 1)
     DFLT(2, 0, 4, 8, 1)
 }
-template <> int dispatch<0, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<0, 1>(const mg3d_options &o, SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(0, 1, 4, 8, 1) TRY(0, 1, 8, 4, 2) TRY(0, 1, 4, 8, 2) TRY(0, 1, 4, 8, 3) TRY(0, 1, 2, 8, 4) TRY(0, 1, 2, 16, 1)
     DFLT(0, 1, 4, 8, 1)
@@ -349,12 +317,12 @@ template <> int dispatch<0, 1>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
 
 /* S colour passes starting with colour c1, optional residual.  Returns the number of
  * partial sums written (0 when no norm was requested), -1 if the shape is unsupported. */
-template <> int dispatch<0, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<0, 2>(const mg3d_options &o, SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(0, 2, 4, 8, 1) TRY(0, 2, 4, 8, 2) TRY(0, 2, 2, 8, 2) TRY(0, 2, 2, 8, 4) TRY(0, 2, 2, 16, 1) TRY(0, 2, 6, 8, 1)
     DFLT(0, 2, 4, 8, 1)
 }
-template <> int dispatch<4, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<4, 2>(const mg3d_options &o, SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     /* the whole down-leg of a level in ONE launch.  The six-stage window only fits two rows per thread (16-row tiles
      * with a halo of 6: four owned rows): a quarter of the rows it computes are kept -- for the levels where a launch
@@ -362,64 +330,36 @@ template <> int dispatch<4, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipSt
     TRY(4, 2, 2, 8, 1) TRY(4, 2, 2, 8, 2)
     DFLT(4, 2, 2, 8, 2)
 }
-template <> int dispatch<2, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<2, 2>(const mg3d_options &o, SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(2, 2, 4, 8, 1)
     DFLT(2, 2, 4, 8, 1)
 }
-template <> int dispatch<1, 2>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<1, 2>(const mg3d_options &o, SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     /* the LAST pre-smoothing pass + residual + restriction: the down-leg's only launch on the top level of a cycle whose
      * first three pre-smoothing passes rode on the previous cycle's last launch (k_sweep_tap) */
     TRY(1, 2, 4, 8, 1) TRY(1, 2, 4, 8, 2)
     DFLT(1, 2, 4, 8, 1)
 }
-template <> int dispatch<4, 3>(SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
+template <> int dispatch<4, 3>(const mg3d_options &o, SweepArgs &a, SweepCfg c, int max_partials, hipStream_t s)
 {
     TRY(4, 3, 4, 8, 1)
     DFLT(4, 3, 4, 8, 1)
 }
 
-int k_sweep_small_max() /* levels of at most this many points per side use the two-rows-per-thread shapes */
-{
-    /* 129 since the plane loop lost its guards (round 3): a 129^3 level is 12 tile columns x 21 chunks of 6 planes behind 8
-     * warm-up planes in the four-row shapes -- pipeline fill -- and the lighter two-row step wins: 129^3 problem 0.226 ->
-     * 0.219 ms per cycle, 257^3 0.558 -> 0.553, 513^3 +0.1-0.6 % (round 2 measured the two-row shapes 40 % slower at
-     * 257^3, where bytes count: still so) */
-    const char *e = getenv("MG3D_SMALL_MAX"); /* 0: never */
-    return e ? atoi(e) : 129;
-}
-
-int k_sweep_fuse_leg_max() /* levels of at most this many points per side run a whole leg of the cycle as ONE launch */
-{
-    /* default 0 (never) since round 3: with the guards gone from the plane loop the four-row launches of a 65^3 level
-     * (four passes 12 us + residual / restriction 9 us) undercut the six-stage two-row leg (29 us), which keeps a quarter
-     * of the rows it computes; 513^3: 3.052 against 3.053 ms per cycle, 129^3: 0.233 against 0.239 ms */
-    const char *e = getenv("MG3D_FUSE_LEG_MAX");
-    return e ? atoi(e) : 0;
-}
-
-int k_sweep_fuse_up_max() /* levels of at most this many points per side take the prolongation into a four-pass up-leg launch */
-{
-    const char *e = getenv("MG3D_FUSE_UP_MAX");
-    const int v = e ? atoi(e) : 0;
-    return v > k_sweep_fuse_leg_max() ? v : k_sweep_fuse_leg_max();
-}
-
-bool k_sweep_fuse_rst2(int N) /* two passes + residual + restriction as ONE launch on a level of N points per side? */
+bool k_sweep_fuse_rst2(const mg3d_options &o, int N) /* two passes + residual + restriction as ONE launch on a level of N points per side? */
 {
     /* Since round 3 the shape has no scratch (the restriction overwrites its r pairs in place and parks them in LDS: 243
      * VGPRs; round 2: 156 bytes of scratch, 1.49 ms at 513^3 against 0.63 + 0.57 ms as two launches) and one launch
      * moves 3.4 GB instead of 5.5: V(1,1) at 513^3 2.70 -> 2.28 ms per cycle, 257^3 0.491 -> 0.460; at 129^3 and below
-     * (0.180 -> 0.195 ms) the split launches' two-row shapes stay ahead.  MG3D_FUSE_RST2=1 / 0: always / never (read per
-     * stage, so that a test can compare both routes in one process). */
-    const char *e = getenv("MG3D_FUSE_RST2");
-    if (e && (e[0] == '0' || e[0] == '1'))
-        return e[0] == '1';
+     * (0.180 -> 0.195 ms) the split launches' two-row shapes stay ahead.  Option fuse_rst2 = 1 / 0: always / never. */
+    if (o.v[MG3D_OPT_FUSE_RST2] == 0 || o.v[MG3D_OPT_FUSE_RST2] == 1)
+        return o.v[MG3D_OPT_FUSE_RST2] == 1;
     return N >= 130;
 }
 
-static int sweep_impl(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
+static int sweep_impl(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
                       int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo, int acc_hi,
                       const Geom *gc, double *dc, int ic_lo, int ic_hi, const Geom *gce, const double *ec, int i_lo, int i_hi,
                       bool tap)
@@ -460,48 +400,48 @@ static int sweep_impl(const Geom &g, const double *vin, const double *d, double 
     if (tap) { /* four passes, the residual norm of the state after the second one into partials */
         if (S != 4 || dc || ec || r || !partials || residual)
             return -1;
-        return dispatch<4, 3>(a, env_cfg({4, 8, 1}), max_partials, s);
+        return dispatch<4, 3>(o, a, opt_cfg(o, {4, 8, 1}), max_partials, s);
     }
     if (ec) { /* prolongation fused into the input: 4- and 2-pass smoothing launches */
         if (dc || residual || (g.nj & 1) == 0 || c1 != 0) /* (c1: the kernel derives the plane parity from it, see PRO) */
             return -1;
         if (S == 4) /* small levels: two rows per thread (no spills, 8 owned rows of 16); else the opt-in four-row shape */
-            return g.N <= k_sweep_small_max() ? launch_sweep<4, 0, 2, 8, 2, true>(a, max_partials, s)
-                                              : launch_sweep<4, 0, 4, 8, 1, true>(a, max_partials, s);
+            return g.N <= o.v[MG3D_OPT_SMALL_MAX] ? launch_sweep<4, 0, 2, 8, 2, true>(o, a, max_partials, s)
+                                              : launch_sweep<4, 0, 4, 8, 1, true>(o, a, max_partials, s);
         if (S == 2)
-            return launch_sweep<2, 0, 4, 8, 1, true>(a, max_partials, s);
+            return launch_sweep<2, 0, 4, 8, 1, true>(o, a, max_partials, s);
         return -1;
     }
     /* Levels of at most 65^3 points: a step costs a global-load latency (~1.4 us with one plane in flight), not
      * bandwidth, and only a few tiles exist anyway -- two rows per thread leave the registers for two planes in flight
      * (33^3: four passes 20 -> 13 us, residual + restriction 15 -> 12 us; at 257^3 the same shapes are 40 % slower). */
-    const bool small = g.N <= k_sweep_small_max();
+    const bool small = g.N <= o.v[MG3D_OPT_SMALL_MAX];
     if (dc && S == 0 && residual)
-        return dispatch<0, 2>(a, env_cfg(small ? SweepCfg{2, 8, 2} : SweepCfg{4, 8, 1}), max_partials, s);
+        return dispatch<0, 2>(o, a, opt_cfg(o, small ? SweepCfg{2, 8, 2} : SweepCfg{4, 8, 1}), max_partials, s);
     if (dc && S == 2 && residual)
-        return dispatch<2, 2>(a, env_cfg({4, 8, 1}), max_partials, s);
+        return dispatch<2, 2>(o, a, opt_cfg(o, {4, 8, 1}), max_partials, s);
     if (dc && S == 1 && residual)
-        return dispatch<1, 2>(a, env_cfg({4, 8, 1}), max_partials, s);
+        return dispatch<1, 2>(o, a, opt_cfg(o, {4, 8, 1}), max_partials, s);
     if (dc && S == 4 && residual)
-        return dispatch<4, 2>(a, env_cfg({2, 8, 2}), max_partials, s);
+        return dispatch<4, 2>(o, a, opt_cfg(o, {2, 8, 2}), max_partials, s);
     if (dc)
         return -1;
     if (S == 4 && residual)
-        return dispatch<4, 1>(a, env_cfg({6, 4, 2}), max_partials, s);
+        return dispatch<4, 1>(o, a, opt_cfg(o, {6, 4, 2}), max_partials, s);
     if (S == 4 && !residual)
-        return dispatch<4, 0>(a, env_cfg(small ? SweepCfg{2, 8, 2} : SweepCfg{4, 8, 1}), max_partials, s);
+        return dispatch<4, 0>(o, a, opt_cfg(o, small ? SweepCfg{2, 8, 2} : SweepCfg{4, 8, 1}), max_partials, s);
     if (S == 2 && residual) {
         /* the norm alone (the top level's second post-smoothing launch): a shape without the code that assembles r */
-        const SweepCfg c = env_cfg({4, 8, 1});
-        if (!r && c.rj == 4 && c.nw == 8 && (c.pf == 1 || c.pf == 2) && !getenv("MG3D_NO_NORM_ONLY"))
-            return c.pf == 1 ? launch_sweep<2, 1, 4, 8, 1, false, false>(a, max_partials, s)
-                             : launch_sweep<2, 1, 4, 8, 2, false, false>(a, max_partials, s);
-        return dispatch<2, 1>(a, c, max_partials, s);
+        const SweepCfg c = opt_cfg(o, {4, 8, 1});
+        if (!r && c.rj == 4 && c.nw == 8 && (c.pf == 1 || c.pf == 2))
+            return c.pf == 1 ? launch_sweep<2, 1, 4, 8, 1, false, false>(o, a, max_partials, s)
+                             : launch_sweep<2, 1, 4, 8, 2, false, false>(o, a, max_partials, s);
+        return dispatch<2, 1>(o, a, c, max_partials, s);
     }
     if (S == 2 && !residual)
-        return dispatch<2, 0>(a, env_cfg(small ? SweepCfg{2, 8, 4} : SweepCfg{4, 8, 1}), max_partials, s);
+        return dispatch<2, 0>(o, a, opt_cfg(o, small ? SweepCfg{2, 8, 4} : SweepCfg{4, 8, 1}), max_partials, s);
     if (S == 0 && residual)
-        return dispatch<0, 1>(a, env_cfg({4, 8, 1}), max_partials, s);
+        return dispatch<0, 1>(o, a, opt_cfg(o, {4, 8, 1}), max_partials, s);
     return -1;
 }
 
@@ -553,7 +493,7 @@ static void leg_args(SweepArgs &a, const Geom &g, const double *vin, const doubl
     a.ic_lo = a.ic_hi = 0;
 }
 
-int k_sweep_leg_down(const Geom &g, const double *vin, const double *d, double *vout, const Geom &gc, double *dc, double h, int S,
+int k_sweep_leg_down(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, const Geom &gc, double *dc, double h, int S,
                      double *partials, int max_partials, hipStream_t s, int acc_lo, int acc_hi, int ic_lo, int ic_hi, int i_lo,
                      int i_hi)
 {
@@ -566,15 +506,15 @@ int k_sweep_leg_down(const Geom &g, const double *vin, const double *d, double *
     a.ic_lo = ic_lo >= 0 ? ic_lo : 0;
     a.ic_hi = ic_hi >= 0 ? ic_hi : gc.ni;
     if (S == 4 && !partials)
-        return launch_sweep<4, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN4, -1>(a, max_partials, s);
+        return launch_sweep<4, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN4, -1>(o, a, max_partials, s);
     if (S == 3 && partials)
-        return launch_sweep<3, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN3, 0>(a, max_partials, s);
+        return launch_sweep<3, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN3, 0>(o, a, max_partials, s);
     if (S == 3)
-        return launch_sweep<3, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN3, -1>(a, max_partials, s);
+        return launch_sweep<3, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN3, -1>(o, a, max_partials, s);
     return -1;
 }
 
-int k_sweep_leg_up(const Geom &g, const double *vin, const double *d, double *vout, const Geom &gce, const double *ec, double h,
+int k_sweep_leg_up(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, const Geom &gce, const double *ec, double h,
                    double *partials, int max_partials, hipStream_t s, int acc_lo, int acc_hi, int i_lo, int i_hi)
 {
     if ((g.nj & 1) == 0)
@@ -586,21 +526,21 @@ int k_sweep_leg_up(const Geom &g, const double *vin, const double *d, double *vo
     a.ec = ec;
     a.gce = gce;
     if (partials)
-        return launch_sweep<4, 0, 8, 4, 1, true, true, MG3D_LEG_DP_UP, 4>(a, max_partials, s);
-    return launch_sweep<4, 0, 8, 4, 1, true, true, MG3D_LEG_DP_UP, -1>(a, max_partials, s);
+        return launch_sweep<4, 0, 8, 4, 1, true, true, MG3D_LEG_DP_UP, 4>(o, a, max_partials, s);
+    return launch_sweep<4, 0, 8, 4, 1, true, true, MG3D_LEG_DP_UP, -1>(o, a, max_partials, s);
 }
 
-int k_sweep(const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
+int k_sweep(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
             int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo, int acc_hi,
             const Geom *gc, double *dc, int ic_lo, int ic_hi, const Geom *gce, const double *ec, int i_lo, int i_hi)
 {
-    return sweep_impl(g, vin, d, vout, r, partials, max_partials, h, S, c1, residual, s, acc_lo, acc_hi, gc, dc, ic_lo, ic_hi,
+    return sweep_impl(o, g, vin, d, vout, r, partials, max_partials, h, S, c1, residual, s, acc_lo, acc_hi, gc, dc, ic_lo, ic_hi,
                       gce, ec, i_lo, i_hi, false);
 }
 
-int k_sweep_tap(const Geom &g, const double *vin, const double *d, double *vout, double *partials, int max_partials,
+int k_sweep_tap(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, double *partials, int max_partials,
                 double h, int c1, hipStream_t s, int acc_lo, int acc_hi, int i_lo, int i_hi)
 {
-    return sweep_impl(g, vin, d, vout, nullptr, partials, max_partials, h, 4, c1, false, s, acc_lo, acc_hi, nullptr, nullptr,
+    return sweep_impl(o, g, vin, d, vout, nullptr, partials, max_partials, h, 4, c1, false, s, acc_lo, acc_hi, nullptr, nullptr,
                       -1, -1, nullptr, nullptr, i_lo, i_hi, true);
 }

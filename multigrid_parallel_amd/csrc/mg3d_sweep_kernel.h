@@ -21,8 +21,7 @@ struct SweepArgs {
     int ntj, ntk;   /* tiles in j, k */
     int vk, hk;     /* k-tiling: tile tk covers columns [vk*tk, vk*tk + 128) and owns those at least hk from its
                        edges (a tile edge on the global boundary needs no halo); vk = 128 - 2*hk */
-    int snap;       /* segment cuts closer than this to a tile column's end move onto it */
-    int CI;         /* > 0: lock-step mode, planes per i-chunk; 0: equal shares of the linearised work */
+    int CI;         /* planes per i-chunk (lock-step chunks: block -> (tile column, chunk), tile fastest) */
     int i_lo, i_hi;     /* local output planes this launch produces */
     int acc_lo, acc_hi; /* local planes whose diff^2 enter the norm (owned planes of a slab) */
     /* fused prolongation (PRO): the level's input is vin + P(ec) (mg_3d.h:1000-1145); gce = geometry of ec */
@@ -32,9 +31,7 @@ struct SweepArgs {
     Geom gc;
     double *dc;
     int ic_lo, ic_hi;
-    int xcd_remap;  /* 1: blocks of one XCD group (blockIdx % 8) take consecutive shares of the work */
-    int rev;        /* 1: the i-chunks are handed out last to first (the launch before it ended on the last planes: what of
-                       them is still in the Infinity Cache is read first).  Speed only. */
+    int xcd_remap;  /* 1: blocks of one XCD group (blockIdx % 8) take consecutive shares of the work; 2: per chunk layer */
 };
 
 /* RES: 0 = smoothing only, 1 = + residual (r store and/or norm), 2 = + residual AND full-weighting
@@ -205,10 +202,7 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
     const int lane = threadIdx.x & (WAVE - 1);
     const int w = (MG3D_UNIFORM_W == 2 || (MG3D_UNIFORM_W == 1 && RES != 0)) ? __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE)
                                                                              : (int)(threadIdx.x / WAVE);
-    /* this block's work: in lock-step mode one segment (tile column t_lin, planes off .. off+len of the output range);
-     * in the balanced experiment its share [w0, w1) of the linearised (tile column, output plane) space, one or two
-     * segments.  The 64-bit divisions of the latter are ~1400 instructions of prologue (5-6 us per launch, a quarter
-     * of a whole launch on the levels below 129^3): they stay behind the mode test. */
+    /* this block's work: one segment -- tile column t_lin, planes off .. off + len of the output range */
     const int nout = a.i_hi - a.i_lo;
     int vb = blockIdx.x;
     if (a.xcd_remap == 1) {
@@ -217,14 +211,12 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
         const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = vb & 7, idx = vb >> 3;
         vb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
     }
-    long long w0 = 0, w1 = 0;
     int t_lin = 0, off = 0, len = 0;
-    const bool lockstep = a.CI > 0;
-    if (lockstep) {
+    {
         /* block -> (tile column, i-chunk), tile fastest: all tile columns of a chunk march through the same planes at
          * the same time, so a neighbour's halo rows are still in the Infinity Cache / L2 */
         const int T = a.ntj * a.ntk;
-        int ch = vb / T;
+        const int ch = vb / T;
         int tl = vb - ch * T;
         if (a.xcd_remap == 2) {
             /* several rounds of blocks: inside every chunk's layer of T blocks, the blocks of one XCD group take a
@@ -239,38 +231,11 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
             tl = o + (tl - ((x - r0 + 8) & 7)) / 8;
         }
         t_lin = tl;
-        if (a.rev)
-            ch = (int)(gridDim.x / T) - 1 - ch;
         off = ch * a.CI;
         len = min(a.CI, nout - off);
-    } else {
-        const long long W = (long long)a.ntj * a.ntk * nout;
-        auto cut = [&](int k) -> long long {
-            long long x = W * k / gridDim.x;
-            const int r = (int)(x % nout);
-            if (r < a.snap)
-                x -= r;
-            else if (nout - r < a.snap)
-                x += nout - r;
-            return x;
-        };
-        w0 = cut(vb);
-        w1 = cut(vb + 1);
     }
     double acc = 0.;
 
-    for (bool more = true; more;) {
-    if (lockstep) {
-        more = false;
-    } else {
-        if (w0 >= w1)
-            break;
-        t_lin = (int)(w0 / nout);
-        off = (int)(w0 - (long long)t_lin * nout);
-        len = (int)min((long long)(nout - off), w1 - w0);
-        w0 += len;
-        more = w0 < w1;
-    }
     const int tk = t_lin % a.ntk, tj = t_lin / a.ntk;
 
     const int jt0 = tj * VJ - HJ, kt0 = tk * a.vk;
@@ -876,7 +841,6 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
     }
     if (pl < nsteps)
         step(pl, std::integral_constant<int, 0>{});
-    } /* segments */
 
     if (NORM && a.partials) {
 #pragma unroll

@@ -15,11 +15,12 @@ from test_gpu_parity import EXACT_NORM_RTOL, assert_norm_exact, norm_rtol
 pytestmark = pytest.mark.gpu
 
 
-def _legs(monkeypatch, on):
-    monkeypatch.setenv("MG3D_CARRY_MIN", "66")  # both schedules from 129^3 up in these tests (default: 257^3)
-    monkeypatch.setenv("MG3D_LEGS_MIN", "66")
-    monkeypatch.setenv("MG3D_LEGS", "1" if on else "0")
-    monkeypatch.setenv("MG3D_NO_CARRY", "0" if on else "1")
+def _legs(s, on):
+    """the schedule under test through the options API (mg3d_ctx_set_option), from 129^3 up (default: 130 points a side)"""
+    s.set_option("legs_min", 66)
+    s.set_option("legs", 1 if on else 0)
+    s.set_option("carry", 0)  # (the other schedule in these tests is the plain one: one launch per operator group)
+    return s
 
 
 @pytest.mark.parametrize("c,L,calls", [(9, 5, (5,)), (5, 6, (1, 2, 3)), (3, 7, (4, 1)), (17, 4, (6,)), (9, 6, (3,)), (11, 5, (3,))])
@@ -30,8 +31,8 @@ def test_one_launch_per_leg_equals_the_plain_schedule_and_the_oracle(monkeypatch
     tile arithmetic; (17, 4): a 17^3 coarsest grid.)"""
     res = []
     for on in (True, False):
-        _legs(monkeypatch, on)
         with M.Solver(c, L, 2) as s:
+            _legs(s, on)
             s.setup_test_problem()
             norms = []
             for k in calls:
@@ -53,8 +54,9 @@ def test_every_norm_of_a_batch_is_the_exactly_rounded_one(monkeypatch):
     by a third: every cycle's value, not only the last, against the exactly rounded sum over the oracle's residual field
     of that cycle's u (taken from a second solver stepped one cycle at a time)."""
     c, L, K = 9, 5, 5
-    _legs(monkeypatch, True)
     with M.Solver(c, L, 2) as batch, M.Solver(c, L, 2) as step:
+        _legs(batch, True)
+        _legs(step, True)
         batch.setup_test_problem()
         step.setup_test_problem()
         got = batch.vcycles(K)
@@ -78,9 +80,9 @@ def test_single_cycle_calls_run_the_next_down_leg_ahead_and_other_calls_swap_it_
     d2 = np.random.default_rng(77).uniform(-1, 1, N ** 3)
     logs = []
     for on in (True, False):
-        _legs(monkeypatch, on)
         log = []
         with M.Solver(c, L, 2) as s:
+            _legs(s, on)
             top = L - 1
             s.setup_test_problem()
             s.timing_enable(1)
@@ -102,11 +104,10 @@ def test_single_cycle_calls_run_the_next_down_leg_ahead_and_other_calls_swap_it_
             log += list(s.vcycles(3))                     # a batch call behind single ones continues from the state run ahead
             log.append(s.vcycle())
             if on:                                        # the switch thrown while a down-leg has run ahead
-                monkeypatch.setenv("MG3D_LEGS", "0")
-                monkeypatch.setenv("MG3D_NO_CARRY", "1")
+                s.set_option("legs", 0)
             log.append(s.vcycle())
             if on:
-                _legs(monkeypatch, True)
+                s.set_option("legs", 1)
             log.append(s.vcycle())
             log.append(s.vcycle(top - 1))                 # a cycle from a lower level
             log.append(s.vcycle())
@@ -133,14 +134,13 @@ def test_single_cycle_calls_run_the_next_down_leg_ahead_and_other_calls_swap_it_
 def test_leg_launches_are_taken_and_counted(monkeypatch):
     """K cycles of one call: K up-leg and K down-leg launches on the top level, one norm-only launch (the last cycle's) and
     the first cycle's face injection, nothing else there; off by default."""
-    _legs(monkeypatch, True)
     with M.Solver(9, 5, 2) as s:
+        _legs(s, True)
         s.setup_test_problem()
         s.timing_enable(1)
         s.vcycles(5)
         kt = {kn: n for (lvl, kn), (n, _) in s.kernel_times().items() if lvl == 4}
     assert kt == {"leg_up": 5, "leg_down": 5, "residual": 1, "restrict": 1}, kt  # (restrict: the face injection, first cycle only)
-    monkeypatch.delenv("MG3D_LEGS")
     with M.Solver(9, 5, 2) as s:
         s.setup_test_problem()
         s.timing_enable(1)
@@ -157,8 +157,8 @@ def test_right_hand_side_and_scale_do_not_matter(monkeypatch):
         d, u0 = rng.uniform(-1, 1, N ** 3) * scale, rng.uniform(-1, 1, N ** 3) * scale
         res = []
         for on in (True, False):
-            _legs(monkeypatch, on)
             with M.Solver(c, L, 2) as s:
+                _legs(s, on)
                 s.get_details()
                 s.upload(MG3D_D, L - 1, d)
                 s.upload(MG3D_U, L - 1, u0)

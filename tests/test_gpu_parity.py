@@ -412,8 +412,10 @@ def test_on_the_fly_restriction_equals_materialised_residual(c, L, nu):
 
 @pytest.mark.parametrize("c,L,nu", [(5, 5, 2), (9, 4, 1), (5, 4, 3), (3, 6, 2), (9, 5, 2)])
 def test_prolongation_fused_into_smoother_equals_separate_launch(c, L, nu, monkeypatch):
-    """MG3D_PRO_FUSE=1 folds prolongateAndCorrectError into the post-smoother's loads (opt-in: measured slower);
-    by default it is its own kernel.  Same bits either way (and both equal the oracle, see the history tests)."""
+    """Option fuse_up_max (here through its environment override, read when the context is created) folds
+    prolongateAndCorrectError into the post-smoother's four-pass launch on every level (opt-in: measured slower above
+    the two-row shapes); by default it is its own kernel below the top level.  Same bits either way (and both equal the
+    oracle, see the history tests)."""
     import subprocess, sys, json
     outs = []
     for flag in ("0", "1"):
@@ -421,7 +423,7 @@ def test_prolongation_fused_into_smoother_equals_separate_launch(c, L, nu, monke
                 f"import numpy as np, multigrid_parallel_amd as M;"
                 f"s=M.Solver({c},{L},{nu}); s.setup_test_problem(); n=s.vcycles(5);"
                 f"u=s.download(0,{L - 1}); print(json.dumps([list(n), hashlib.sha256(u.tobytes()).hexdigest()]))")
-        env = dict(os.environ, MG3D_PRO_FUSE=flag)
+        env = dict(os.environ, MG3D_FUSE_UP_MAX="100000" if flag == "1" else "0")
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
@@ -760,10 +762,10 @@ def test_single_cycle_calls_run_ahead_and_other_calls_put_the_result_back(monkey
             log += list(s.vcycles(3))                    # a batch call behind single ones
             log.append(s.vcycle())
             if flag == "0":                              # the switch thrown while a cycle is carried: it is finished first
-                monkeypatch.setenv("MG3D_NO_CARRY", "1")
+                s.set_option("carry", 0)
             log.append(s.vcycle())
             if flag == "0":
-                monkeypatch.setenv("MG3D_NO_CARRY", "0")
+                s.set_option("carry", 1)
             log.append(s.vcycle())
             log.append(s.vcycle(top - 1))                # a cycle from a lower level
             log.append(s.vcycle())
@@ -832,8 +834,8 @@ def test_measured_chunk_length_changes_no_bit(monkeypatch):
     the cost model's choice; MG3D_SWEEP_CI: a fixed one).  Chunking is a work distribution only: same grid values (the norm is a sum of per-block partial sums).""" 
     c, L, nu = 9, 5, 2  # 129^3: large enough for the measurement to run
     res = []
-    for env in ({"MG3D_SWEEP_TUNE": "0"}, {}, {"MG3D_SWEEP_CI": "5"}, {"MG3D_SWEEP_TAIL": "1", "MG3D_SWEEP_TUNE": "0"}, {}):
-        for k in ("MG3D_SWEEP_TUNE", "MG3D_SWEEP_CI", "MG3D_SWEEP_TAIL"):
+    for env in ({"MG3D_SWEEP_TUNE": "0"}, {}, {"MG3D_SWEEP_CI": "5"}, {"MG3D_SWEEP_CI": "23", "MG3D_SWEEP_TUNE": "0"}, {}):
+        for k in ("MG3D_SWEEP_TUNE", "MG3D_SWEEP_CI"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -898,3 +900,35 @@ def test_two_host_threads_solve_concurrently():
     for t in range(2):
         assert np.array_equal(out[t][1], want_u)
         np.testing.assert_allclose(out[t][0], want_norms, rtol=norm_rtol((c - 1) * (1 << (L - 1)) + 1))
+
+
+def test_options_are_per_context_and_set_through_the_api(monkeypatch):
+    """mg3d_ctx_set_option / _get_option: the launch policy belongs to a context -- defaults, the environment as an override
+    when the context is created, the API afterwards.  Two contexts of one process differ; the environment is not read
+    again after creation; unknown keys are refused; the grid values do not depend on any of it."""
+    monkeypatch.delenv("MG3D_NO_CARRY", raising=False)
+    monkeypatch.setenv("MG3D_CARRY_MIN", "66")
+    with M.Solver(9, 5, 2) as a, M.Solver(9, 5, 2) as b:
+        assert a.get_option("carry") == 1 and a.get_option("carry_min") == 66 and a.get_option("legs") == 0
+        assert set(a.options()) >= {"carry", "carry_min", "legs", "legs_min", "tiny", "tiny_cycle", "lu_reduced", "fuse_rst2",
+                                    "small_max", "fuse_leg_max", "fuse_up_max", "sweep_tune", "sweep_ci"}
+        monkeypatch.setenv("MG3D_NO_CARRY", "1")  # after creation: nobody reads it any more
+        b.set_option("carry", 0)
+        b.set_option("small_max", 0)
+        b.set_option("tiny_cycle", 0)
+        for s in (a, b):
+            s.setup_test_problem()
+            s.timing_enable(1)
+        na, nb = a.vcycles(4), b.vcycles(4)
+        ka = {kn for (lvl, kn), (n, _) in a.kernel_times().items() if lvl == 4}
+        kb = {kn for (lvl, kn), (n, _) in b.kernel_times().items() if lvl == 4}
+        assert "sweep4+norm" in ka and "sweep4+norm" not in kb, (ka, kb)
+        for l in range(5):
+            assert np.array_equal(a.download(MG3D_U, l), b.download(MG3D_U, l)), l
+        np.testing.assert_allclose(na, nb, rtol=1e-12)
+        with pytest.raises(M.Mg3dError):
+            a.set_option("no_such_option", 1)
+        with pytest.raises(M.Mg3dError):
+            a.get_option("no_such_option")
+    with M.Solver(9, 5, 2) as c:  # created with MG3D_NO_CARRY=1 in the environment: the override is taken at creation
+        assert c.get_option("carry") == 0

@@ -52,15 +52,13 @@ for name, (fn, alg, cfgs) in cases.items():
     if only and name not in only.split(","):
         continue
     for cfg in (cfg_override.split(";") if cfg_override else cfgs):
-        os.environ["MG3D_SWEEP_CFG"] = cfg
+        rj, nw, pf = (int(x) for x in cfg.split(","))
+        for key, v in (("sweep_rj", rj), ("sweep_nw", nw), ("sweep_pf", pf)):  # the options API: nothing reads the environment per launch
+            s.set_option(key, v)
         for ci in os.environ.get("CIS", "0").split(","):
-            os.environ["MG3D_SWEEP_CI"] = ci
-            for xcd in os.environ.get("XCDS", "0").split(","):
-                os.environ["MG3D_XCD"] = xcd
-                for vk in os.environ.get("VKS", "0").split(","):  # 0: line-aligned k-tiles when free, 1: tightest packing
-                    os.environ["MG3D_SWEEP_VK"] = vk
-                    t = timeit(fn)
-                    print(f"{name:6s} cfg {cfg:6s} CI {ci:>3s} xcd {xcd} vk {vk}: {t * 1e3:8.3f} ms   algorithmic {alg / t / 1e9:8.1f} GB/s", flush=True)
+            s.set_option("sweep_ci", int(ci))
+            t = timeit(fn)
+            print(f"{name:6s} cfg {cfg:6s} CI {ci:>3s}: {t * 1e3:8.3f} ms   algorithmic {alg / t / 1e9:8.1f} GB/s", flush=True)
 if os.environ.get("NO_UNFUSED"):
     sys.exit(0)
 os.environ["MG3D_NO_FUSE"] = "1"
