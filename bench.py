@@ -169,6 +169,25 @@ def self_launch(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+def f32_roofline(launches_tab, comp, alg, per, world, steps):
+    """dominant finest-level launch (by total time) with its compulsory bytes / mean duration / 8 TB/s, the other launches
+    beside it; without kernel timers (slabs) the whole cycle against its compulsory bytes"""
+    whole = {"vcycle_compulsory_gb": comp / 1e9, "vcycle_frac_of_hbm_peak": comp / per / 1e9 / (HBM_PEAK_GBS * world),
+             "vcycle_frac_survey_credit": alg / per / 1e9 / (HBM_PEAK_GBS * world)}
+    if not launches_tab:
+        return dict({"bound": "hbm", "kernel": "whole V-cycle (compulsory bytes: every leg streams its fields once, w = 4)",
+                     "achieved": comp / per / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                     "frac": comp / per / 1e9 / (HBM_PEAK_GBS * world), "traffic": None}, **whole)
+    dom = max(launches_tab, key=lambda r: r["ms"] * r["launches"])
+    ach = dom["compulsory_bytes"] / (dom["ms"] * 1e-3) / 1e9
+    return dict({"bound": "hbm", "kernel": f"fp32 finest level: {dom['what']} [timer {dom['kernel']}]", "achieved": ach,
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                 "bytes_per_launch": dom["compulsory_bytes"], "bytes_definition": "compulsory: inputs read once + outputs written once",
+                 "avg_launch_ms": dom["ms"], "launches_timed": dom["launches"], "finest_level_launches": launches_tab,
+                 "finest_level_ms_per_cycle": sum(r["ms"] * r["launches"] for r in launches_tab) / max(1, steps)},
+                **whole)
+
+
 def f32_line(args):
     """One JSON line for the fp32 / damped-Jacobi / F-cycle variant (BASELINE configs[4]; parity unpinned).  Not the
     headline metric.  --gpus N > 1 (under torch.distributed.run, or self-launched): the same problem on N i-slabs."""
@@ -213,6 +232,30 @@ def f32_line(args):
     norms = s.vcycles(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    # per-launch roofline of the finest level (single domain): the same cycles once more with the kernel timers on (event
+    # pairs on the library's stream; kept out of `value`'s timed region: a marker packet is ~5 us of idle queue)
+    launches_tab = []
+    if world == 1 and not force_dist:
+        s.timing_enable(True)
+        s.vcycles(args.steps)
+        s.timing_enable(False)
+        n_f, n_c, w = N ** 3, (((N - 1) // 2) + 1) ** 3, 4
+        kinds = {  # kernel timer -> (what one launch does, compulsory bytes: inputs read once + outputs written once)
+            "pair": ("two damped-Jacobi sweeps", 3 * n_f * w),
+            "pair+tap": ("two sweeps + the previous cycle's residual norm tapped from the first sweep's sums", 3 * n_f * w),
+            "prolong+pair": ("prolongation + two sweeps", 3 * n_f * w + n_c * w),
+            "prolong+pair+norm": ("prolongation + two sweeps + residual norm (third stage)", 3 * n_f * w + n_c * w),
+            "pair+norm": ("two sweeps + residual norm", 3 * n_f * w),
+            "residual+restrict": ("residual + full-weighting restriction, r never stored", 2 * n_f * w + n_c * w),
+            "residual": ("residual norm", 2 * n_f * w),
+            "prolong": ("prolongation", 2 * n_f * w + n_c * w),
+            "sweep1": ("one sweep", 3 * n_f * w),
+        }
+        for kn, (calls, secs) in sorted(s.kernel_times().items()):
+            what, comp_l = kinds[kn]
+            ms = secs * 1e3 / calls
+            launches_tab.append({"kernel": kn, "what": what, "launches": calls, "ms": ms, "compulsory_bytes": comp_l,
+                                 "frac": comp_l / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -258,10 +301,8 @@ def f32_line(args):
                        "coarse_pts": c, "levels": L, "smooth_iters": nu, "parallelism": par},
             "fcycle_start_ms": t_fmg * 1e3, "first_norm": float(norms[0]), "last_norm": float(norms[-1]),
             "norm_after_fcycle_start": float(after[0]), "slabs_bit_identical_to_single_domain": slabs_ok,
-            "roofline": {"bound": "hbm", "kernel": "whole V-cycle (compulsory bytes: every leg streams its fields once, w = 4)",
-                         "achieved": comp / per / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                         "frac": comp / per / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
-                         "frac_survey_credit": alg / per / 1e9 / (HBM_PEAK_GBS * world)},
+            "parity": "unpinned: the reference has no fp32 / Jacobi / F-cycle path; bit-identical to the builder's restatement only",
+            "roofline": f32_roofline(launches_tab, comp, alg, per, world, args.steps),
             "cpu_baseline": None}))
     s.close()
     if dist.is_initialized():

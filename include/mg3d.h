@@ -215,8 +215,9 @@ int mg3d_comm_unique_id(void *out128);
 int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters, double grid_length, int rank, int nranks,
                      const void *unique_id, int device, mg3d_dist **out);
 int mg3d_dist_destroy(mg3d_dist *d);
-/* ranks in the RCCL communicator (ncclCommCount; 0 without one), whether the u exchanges overlap the coarser
- * levels on a second stream/communicator (MG3D_OVERLAP=1; default off for RCCL), the HIP device in use */
+/* ranks in the RCCL communicator (ncclCommCount; 0 without one), whether the exchanges run on the communication stream
+ * (one communicator; the u halos then travel underneath the launches in between: the default, MG3D_NO_OVERLAP=1 at
+ * creation keeps everything on the compute stream), the HIP device in use */
 int mg3d_dist_comm_info(const mg3d_dist *d, int *rccl_ranks, int *overlap, int *device);
 int mg3d_dist_first_level(const mg3d_dist *d); /* lowest distributed level */
 int mg3d_dist_halo(const mg3d_dist *d);        /* halo planes per side */
@@ -241,8 +242,9 @@ int mg3d_slab_owned(int coarse_pts, int num_levels, int nranks, int halo, int le
  * `omp for` (mg_3d.h:658-702, 807-842, 961-995, 1007-1145), after which every thread sees its neighbours' planes.
  * A phase = one ncclGroupStart/End (all ranks issue the same phases in the same order); offsets and counts are in planes
  * of `plane_elems` elements: LOCAL plane indices of the rank's slab for distributed levels, global ones for the
- * replicated level's arrays.  stream: 0 compute stream / first communicator, 1 communication stream / second
- * communicator (overlap = 1 only).  policy bit 0: the coarse levels are solved on rank 0 only (right-hand side gathered,
+ * replicated level's arrays.  stream: 0 compute stream (overlap off); overlap on: every exchange is issued on the
+ * communication stream, the only stream that drives the one communicator -- 1 the compute stream joins at once, 2 it joins
+ * when it next needs the field (the transfer runs underneath the launches in between).  policy bit 0: the coarse levels are solved on rank 0 only (right-hand side gathered,
  * correction broadcast: MG3D_COARSE_GATHER=1) instead of replicated on every rank behind one all-gather. */
 enum { MG3D_XK_HALO_U_DOWN = 0, /* u_l after pre-smoothing + restriction, for the prolongation on the way up */
        MG3D_XK_HALO_D,          /* d_(l-1) after restriction */
@@ -269,7 +271,7 @@ typedef struct mg3d_xfer {
 int mg3d_dist_plan(int coarse_pts, int num_levels, int nranks, int smooth_iters, int rank, int overlap, int policy,
                    mg3d_xfer *out, int max_entries);
 /* per-phase cost of the slab path, from event pairs on the streams the phases run on (on = 1; off by default):
- * ms[0] whole cycles, ms[1] exchanges on the compute stream, ms[2] exchanges on the communication stream (overlapped),
+ * ms[0] whole cycles, ms[1] exchanges the compute stream waits for at once, ms[2] exchanges that run overlapped,
  * ms[3] the replicated (or rank-0) coarse levels incl. the direct solve; kernels on the distributed levels =
  * ms[0] - ms[1] - ms[3].  Sums since the last enable; *cycles = cycles covered. */
 int mg3d_dist_timing_enable(mg3d_dist *d, int on);
@@ -340,6 +342,11 @@ int mg3d32_vcycles(mg3d32_ctx *ctx, int count, double *norms);     /* mg_3d.h:12
  * fp64 mg3d_fmg_initialize reproduces), this variant zeroes only the coarser level before descending: the interpolated
  * guess is kept on every level. */
 int mg3d32_fmg_initialize(mg3d32_ctx *ctx);
+/* kernel timers of the finest level's launches (event pairs in-stream, resolved by mg3d32_vcycles' own synchronisation):
+ * mg3d32_kernel_name(k) is NULL past the last kernel */
+int mg3d32_timing_enable(mg3d32_ctx *ctx, int on);
+const char *mg3d32_kernel_name(int kernel);
+int mg3d32_kernel_time_get(mg3d32_ctx *ctx, int kernel, int *num_launches, double *seconds);
 
 /* The same variant on i-slabs of several GPUs (csrc/mg3d_f32_dist.hip; BASELINE configs[4]: 1025^3 on 8 GPUs): the
  * partition and schedule of mg3d_dist_* with H = smooth_iters + 2 halo planes (a Jacobi sweep uses up one plane per

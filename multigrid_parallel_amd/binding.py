@@ -79,6 +79,9 @@ SIGNATURES = {
     "mg3d_ctx_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "mg3d_option_name": (C.c_char_p, [C.c_int]),
     "mg3d32_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "mg3d32_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "mg3d32_kernel_name": (C.c_char_p, [C.c_int]),
+    "mg3d32_kernel_time_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), dp]),
     "mg3d_dist_build_coarse": (C.c_int, [C.c_void_p, C.c_double]),
     "mg3d_dist_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
     "mg3d_dist_download": (C.c_int, [C.c_void_p, C.c_int, C.c_int, dp]),
@@ -536,6 +539,20 @@ class Solver32:
     def set_option(self, key, value):
         """mg3d32_set_option: "pairs", "fuse", "carry" (1 on, 0 off)."""
         check(self.L.mg3d32_set_option(self._h, key.encode(), int(value)))
+
+    def timing_enable(self, on=True):
+        check(self.L.mg3d32_timing_enable(self._h, int(on)))
+
+    def kernel_times(self):
+        """{kernel name: (launches, seconds)} of the finest level's launches since timing_enable(True)"""
+        out, k = {}, 0
+        while self.L.mg3d32_kernel_name(k):
+            n, sec = C.c_int(0), C.c_double(0)
+            check(self.L.mg3d32_kernel_time_get(self._h, k, C.byref(n), C.byref(sec)))
+            if n.value:
+                out[self.L.mg3d32_kernel_name(k).decode()] = (n.value, sec.value)
+            k += 1
+        return out
 
     def level_n(self, level):
         return self.L.mg3d32_level_n(self._h, level)

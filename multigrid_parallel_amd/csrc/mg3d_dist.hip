@@ -123,7 +123,8 @@ static int build_plan(Plan &pl, int c, int L, int P, int nu, int rank, int overl
     const long long pec = plan_plane_elems(G, Nc);
     const int cs = overlap ? 1 : 0;
     for (int l = L - 1; l >= G.ld; l--) { /* down */
-        plan_halo(pl, G, MG3D_XK_HALO_U_DOWN, MG3D_U, l, rank, 0, cs);
+        /* first what the coarser level waits for (its right-hand side), then the large u exchange that hides underneath the
+         * coarser levels: with ONE communicator, driven from one in-order stream, the issue order is the execution order */
         if (l - 1 >= G.ld) {
             plan_halo(pl, G, MG3D_XK_HALO_D, MG3D_D, l - 1, rank, 0, 0);
         } else if (policy & 1) {
@@ -139,6 +140,7 @@ static int build_plan(Plan &pl, int c, int L, int P, int nu, int rank, int overl
         } else {
             plan_rhs_allgather(pl, G);
         }
+        plan_halo(pl, G, MG3D_XK_HALO_U_DOWN, MG3D_U, l, rank, 0, cs);
     }
     if (policy & 1) {
         const int ph = plan_open_phase(pl, MG3D_XK_CORR_BCAST, lc);
@@ -160,6 +162,12 @@ static int build_plan(Plan &pl, int c, int L, int P, int nu, int rank, int overl
     }
     plan_norm(pl, G, L - 1, rank);
     pl.begin.push_back((int)pl.e.size());
+    /* stream: 0 the compute stream (overlap off: every exchange sits where the schedule issues it); overlap on: EVERY
+     * exchange is issued on the communication stream with the one communicator -- 1: the compute stream joins at once
+     * (the exchange is on the critical path), 2: it joins when it next needs the field (the exchange runs underneath the
+     * launches in between: the u halos on the way down, the finest u's halos for the next cycle) */
+    for (auto &e : pl.e)
+        e.stream = !overlap ? 0 : (e.kind == MG3D_XK_HALO_U_DOWN || e.kind == MG3D_XK_HALO_U_NEXT) ? 2 : 1;
     return MG3D_OK;
 }
 
@@ -197,11 +205,10 @@ struct mg3d_dist {
     bool loopback;
     int device;
     ncclComm_t comm;  /* compute-stream collectives and exchanges */
-    ncclComm_t comm2; /* communication-stream exchanges (ncclCommSplit of comm: may run concurrently with it) */
-    bool have_comm, have_comm2;
+    bool have_comm;
     hipStream_t stream; /* every operation of every local rank is ordered on this one stream */
     hipStream_t comm_stream; /* the u halo exchanges that hide under coarser levels / the norm run here */
-    hipEvent_t ev_ready;
+    hipEvent_t ev_ready, ev_now; /* compute -> communication stream ("the data is ready"), and back ("it has arrived") */
     std::vector<hipEvent_t> ev_u; /* per level: "the u halos of this level have arrived" */
     std::vector<char> u_pending;  /* per level: ev_u[l] has been recorded and not yet waited for */
     bool overlap; /* MG3D_NO_OVERLAP=1 keeps every exchange on the compute stream */
@@ -330,6 +337,8 @@ extern "C" int mg3d_dist_destroy(mg3d_dist *D)
         (void)hipEventDestroy(e);
     if (D->ev_ready)
         (void)hipEventDestroy(D->ev_ready);
+    if (D->ev_now)
+        (void)hipEventDestroy(D->ev_now);
     for (auto e : D->ev_u)
         if (e)
             (void)hipEventDestroy(e);
@@ -361,8 +370,6 @@ extern "C" int mg3d_dist_destroy(mg3d_dist *D)
         (void)hipFree(D->d_norms);
     if (D->h_norms)
         (void)hipHostFree(D->h_norms);
-    if (D->have_comm2)
-        (void)ncclCommDestroy(D->comm2);
     if (D->have_comm)
         (void)ncclCommDestroy(D->comm);
     delete D;
@@ -387,28 +394,28 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
     D->ld = mg3d_slab_first_level(coarse_pts, num_levels, nranks, D->H);
     D->loopback = unique_id == nullptr;
     D->device = device;
-    D->have_comm = D->have_comm2 = false;
+    D->have_comm = false;
     D->selftest = nullptr;
     D->stream = nullptr;
     D->h_norms = D->d_norms = nullptr;
     D->comm_stream = nullptr;
-    D->ev_ready = nullptr;
+    D->ev_ready = D->ev_now = nullptr;
     D->phase = 0;
     D->timing = false;
     D->t_cycles = 0;
     for (double &x : D->t_ms)
         x = 0.;
     D->policy = (getenv("MG3D_COARSE_GATHER") && getenv("MG3D_COARSE_GATHER")[0] == '1') ? 1 : 0;
-    /* Overlap of the large u exchanges with the coarser levels (second stream, second communicator).  Loopback:
-     * on by default (plain stream concurrency).  RCCL: OFF by default -- two communicators driven concurrently
-     * from two streams of one device have never run on more than one physical GPU here (one GPU per box), and
-     * RCCL only guarantees progress for that pattern while both of its kernels can be co-resident; until a
-     * multi-GPU run has shown it, every exchange stays on the compute stream with ONE communicator.
-     * MG3D_OVERLAP=1 opts in, MG3D_NO_OVERLAP=1 forces it off (also for loopback). */
+    /* Overlap of the large u exchanges with the launches in between (round 4: ONE communicator).  Every exchange is issued
+     * on the communication stream -- the only stream that ever drives the communicator, so RCCL sees one in-order sequence
+     * of operations, identical on all ranks -- behind an event of the compute stream ("the planes are ready"); the compute
+     * stream joins by an event when it needs the planes: at once for the exchanges on the critical path, later for the u
+     * halos, whose transfers then run underneath the coarser levels / the interior of the next launch.  Default for both
+     * transports (rounds 2-3 needed a second communicator for this and kept it off for RCCL); MG3D_NO_OVERLAP=1 keeps
+     * every exchange on the compute stream. */
     {
         const bool off = getenv("MG3D_NO_OVERLAP") && getenv("MG3D_NO_OVERLAP")[0] == '1';
-        const bool on = getenv("MG3D_OVERLAP") && getenv("MG3D_OVERLAP")[0] == '1';
-        D->overlap = !off && (D->loopback || on);
+        D->overlap = !off;
     }
     if (D->ld >= num_levels) {
         delete D;
@@ -486,6 +493,7 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
     }
     DCHK(hipStreamCreateWithFlags(&D->comm_stream, hipStreamNonBlocking));
     DCHK(hipEventCreateWithFlags(&D->ev_ready, hipEventDisableTiming));
+    DCHK(hipEventCreateWithFlags(&D->ev_now, hipEventDisableTiming));
     D->ev_u.assign(num_levels, nullptr);
     D->u_pending.assign(num_levels, 0);
     for (int l = D->ld; l < num_levels; l++)
@@ -514,18 +522,6 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
             const Geom &gt = D->rs[0].dl.back().lv.g;
             if (hipMalloc(&D->selftest, (size_t)D->H * gt.plane * sizeof(double)) != hipSuccess)
                 D->selftest = nullptr;
-        }
-        /* a second communicator for the communication stream: two RCCL operations may only be in flight
-         * together on different communicators.  Without it the exchanges stay on the compute stream. */
-        if (D->overlap) {
-            e = ncclCommSplit(D->comm, 0, rank, &D->comm2, nullptr);
-            if (e == ncclSuccess)
-                D->have_comm2 = true;
-            else {
-                fprintf(stderr, "libmg3d: ncclCommSplit failed (%s): halo exchanges will not be overlapped\n",
-                        ncclGetErrorString(e));
-                D->overlap = false;
-            }
         }
     }
     /* the plan every exchange below is read from; built after the overlap decision is final */
@@ -731,7 +727,7 @@ extern "C" int mg3d_dist_sync(mg3d_dist *D)
  * is -- a mismatch means schedule and plan have come apart, and nothing is sent.  RCCL: one group of the rank's
  * sends / receives / broadcasts exactly as listed.  Loopback: every send is copied into the receive entry that names it
  * in the peer's plan of the same phase (counts must agree), every broadcast range from the root's array into all others. */
-static int run_phase(mg3d_dist *D, int kind, int level, hipStream_t s)
+static int run_phase(mg3d_dist *D, int kind, int level, hipStream_t s, int bucket = 1 /* timer: 1 waited for at once, 2 overlapped */)
 {
     const int ph = D->phase++;
     for (auto &pl : *D->cur)
@@ -748,7 +744,7 @@ static int run_phase(mg3d_dist *D, int kind, int level, hipStream_t s)
             const int n = D->H - (kind == MG3D_XK_HALO_U_NEXT ? 1 : 0);
             const size_t cnt = (size_t)n * a.lv.g.plane;
             const int field = kind == MG3D_XK_HALO_D ? MG3D_D : MG3D_U;
-            ncclComm_t comm = (s == D->comm_stream && D->have_comm2) ? D->comm2 : D->comm;
+            ncclComm_t comm = D->comm;
             NCCLCHK(ncclGroupStart());
             NCCLCHK(ncclSend(a.lv.f[field] + a.lv.g.plane * a.own_lo, cnt, ncclDouble, 0, comm, s));
             NCCLCHK(ncclRecv(D->selftest, cnt, ncclDouble, 0, comm, s));
@@ -756,29 +752,39 @@ static int run_phase(mg3d_dist *D, int kind, int level, hipStream_t s)
         }
         return MG3D_OK;
     }
-    DistScope timer(D, s == D->comm_stream ? 2 : 1, s);
+    DistScope timer(D, bucket, s);
     auto base = [&](size_t ri, const mg3d_xfer &e) -> double * {
         RankState &R = D->rs[ri];
         return e.level >= D->ld ? SL(D, R, e.level).lv.f[e.field] : R.coarse->lv[e.level].f[e.field];
     };
     auto sumsq = [&](size_t ri) -> double * { return D->rs[ri].coarse->sumsq; };
-    ncclComm_t comm = (s == D->comm_stream && D->have_comm2) ? D->comm2 : D->comm;
-    return plan_run<double>(*D->cur, ph, D->loopback, comm, ncclDouble, s, base, sumsq, D->rs[0].gather);
+    return plan_run<double>(*D->cur, ph, D->loopback, D->comm, ncclDouble, s, base, sumsq, D->rs[0].gather);
 }
 
-/* Start refreshing the u halos of level l behind everything queued on the compute stream so far, without
- * holding the compute stream up; await_u() makes the compute stream wait for the arrival. */
-static int start_u_exchange(mg3d_dist *D, int kind, int l)
+/* One exchange phase.  Overlap on (the default): issued on the communication stream -- the one stream that drives the one
+ * communicator -- behind everything queued on the compute stream so far; `defer` = false: the compute stream joins at once
+ * (the exchange is on the critical path), true: it joins in await_u(l), i.e. the transfer runs underneath whatever the
+ * compute stream does until then (u halos of level l only: one pending exchange per level). */
+static int exchange(mg3d_dist *D, int kind, int l, bool defer)
 {
     if (!D->overlap || (D->P == 1 && !D->selftest))
         return run_phase(D, kind, l, D->stream);
     HIPCHK(hipEventRecord(D->ev_ready, D->stream));
     HIPCHK(hipStreamWaitEvent(D->comm_stream, D->ev_ready, 0));
-    CHK(run_phase(D, kind, l, D->comm_stream));
-    HIPCHK(hipEventRecord(D->ev_u[l], D->comm_stream));
-    D->u_pending[l] = 1;
+    CHK(run_phase(D, kind, l, D->comm_stream, defer ? 2 : 1));
+    if (defer) {
+        HIPCHK(hipEventRecord(D->ev_u[l], D->comm_stream));
+        D->u_pending[l] = 1;
+    } else {
+        HIPCHK(hipEventRecord(D->ev_now, D->comm_stream));
+        HIPCHK(hipStreamWaitEvent(D->stream, D->ev_now, 0));
+    }
     return MG3D_OK;
 }
+
+/* Start refreshing the u halos of level l behind everything queued on the compute stream so far, without
+ * holding the compute stream up; await_u() makes the compute stream wait for the arrival. */
+static int start_u_exchange(mg3d_dist *D, int kind, int l) { return exchange(D, kind, l, true); }
 
 static int await_u(mg3d_dist *D, int l)
 {
@@ -793,12 +799,22 @@ static int await_u(mg3d_dist *D, int l)
 static int reduce_norm(mg3d_dist *D, int slot)
 {
     hipStream_t s = D->stream;
-    CHK(run_phase(D, MG3D_XK_NORM, D->L - 1, s));
+    CHK(exchange(D, MG3D_XK_NORM, D->L - 1, false));
     RankState &R = D->rs[0];
     if (D->P == 1 || (!D->loopback && !D->have_comm)) {
-        if (D->P == 1 && D->have_comm) /* forced single-rank communicator: the collective itself (self-test) */
-            NCCLCHK(ncclAllGather(R.coarse->sumsq, R.gather, 1, ncclDouble, D->comm, s));
-        else
+        if (D->P == 1 && D->have_comm) { /* forced single-rank communicator: the collective itself (self-test), on the stream
+                                          * that drives the communicator */
+            hipStream_t xs = (D->overlap && D->selftest) ? D->comm_stream : s;
+            if (xs != s) {
+                HIPCHK(hipEventRecord(D->ev_ready, s));
+                HIPCHK(hipStreamWaitEvent(xs, D->ev_ready, 0));
+            }
+            NCCLCHK(ncclAllGather(R.coarse->sumsq, R.gather, 1, ncclDouble, D->comm, xs));
+            if (xs != s) {
+                HIPCHK(hipEventRecord(D->ev_now, xs));
+                HIPCHK(hipStreamWaitEvent(s, D->ev_now, 0));
+            }
+        } else
             HIPCHK(hipMemcpyAsync(R.gather, R.coarse->sumsq, sizeof(double), hipMemcpyDeviceToDevice, s));
     }
     hipLaunchKernelGGL(sum_in_order_kernel, dim3(1), dim3(64), 0, s, R.gather, D->P, D->d_norms + slot);
@@ -849,6 +865,62 @@ static int stage_smooth(mg3d_dist *D, int l, int post, int want_res, const Restr
         if (S == 0 && refresh_u) { /* u is final; the pure residual launch below reads owned +-1 only */
             CHK(start_u_exchange(D, MG3D_XK_HALO_U_NEXT, l));
             refresh_u = false;
+        }
+        /* Edge windows first (round 4).  The stage's last launch makes the planes the next cycle's halo exchange sends:
+         * the first and last E output planes go first, as ONE launch of two chunks per rank; the exchange is issued behind
+         * it on the communication stream and runs underneath the launch that makes the interior -- instead of sitting
+         * between this launch and the next cycle's first one.  E = the window's margin beyond the owned planes + the planes
+         * the exchange skips + those it sends (carried: 0 + 0 + 3; plain: 1 + 1 + (H - 1)).  Same bits: the chunking of a
+         * sweep launch is a work distribution only, and the norm's per-block partial sums are folded from both launches. */
+        if (last && refresh_u && S > 0 && D->overlap && D->P > 1 && (res || tap) && want_res == 1) {
+            const int margin = tap ? 0 : 1, E = margin + (tap ? 0 : 1) + (tap ? 3 : D->H - 1);
+            std::vector<int> wlo(D->rs.size()), whi(D->rs.size()), npa(D->rs.size());
+            bool ok = true;
+            for (size_t ri = 0; ri < D->rs.size(); ri++) {
+                SlabLevel &sl = SL(D, D->rs[ri], l);
+                wlo[ri] = sl.own_lo - margin < 0 ? 0 : sl.own_lo - margin;
+                whi[ri] = sl.own_hi + margin > sl.lv.g.ni ? sl.lv.g.ni : sl.own_hi + margin;
+                ok = ok && whi[ri] - wlo[ri] >= 2 * E + 2;
+            }
+            if (ok) {
+                auto launch = [&](size_t ri, const double *vin, double *vout, double *part, int lo, int hi, int edge) -> int {
+                    SlabLevel &sl = SL(D, D->rs[ri], l);
+                    Level &lv = sl.lv;
+                    mg3d_ctx *cx = D->rs[ri].coarse;
+                    if (tap)
+                        return k_sweep_tap(cx->opt, lv.g, vin, lv.f[MG3D_D], vout, part, MG3D_MAX_PARTIALS / 2, lv.h, c1, s, sl.own_lo,
+                                           sl.own_hi, lo, hi, edge);
+                    return k_sweep(cx->opt, lv.g, vin, lv.f[MG3D_D], vout, nullptr, part, MG3D_MAX_PARTIALS / 2, lv.h, S, c1, true, s,
+                                   sl.own_lo, sl.own_hi, nullptr, nullptr, -1, -1, (pro && first) ? pro[ri].gc : nullptr,
+                                   (pro && first) ? pro[ri].ec : nullptr, lo, hi, edge);
+                };
+                for (size_t ri = 0; ri < D->rs.size(); ri++) {
+                    Level &lv = SL(D, D->rs[ri], l).lv;
+                    npa[ri] = launch(ri, lv.f[MG3D_U], lv.alt, D->rs[ri].coarse->partials, wlo[ri], whi[ri], E);
+                    if (npa[ri] < 0)
+                        return fail(MG3D_ERR_STATE, "slab sweep: no kernel for the edge windows on level %d", l);
+                }
+                for (auto &R : D->rs) { /* the exchange sends from (and lands in) the NEW buffer */
+                    Level &lv = SL(D, R, l).lv;
+                    double *t = lv.f[MG3D_U];
+                    lv.f[MG3D_U] = lv.alt;
+                    lv.alt = t;
+                }
+                CHK(start_u_exchange(D, MG3D_XK_HALO_U_NEXT, l));
+                refresh_u = false;
+                for (size_t ri = 0; ri < D->rs.size(); ri++) {
+                    Level &lv = SL(D, D->rs[ri], l).lv;
+                    mg3d_ctx *cx = D->rs[ri].coarse;
+                    const int npb = launch(ri, lv.alt, lv.f[MG3D_U], cx->partials + MG3D_MAX_PARTIALS / 2, wlo[ri] + E, whi[ri] - E, 0);
+                    if (npb < 0)
+                        return fail(MG3D_ERR_STATE, "slab sweep: no kernel for the interior window on level %d", l);
+                    k_fold2(cx->partials, npa[ri], cx->partials + MG3D_MAX_PARTIALS / 2, npb, cx->sumsq, s);
+                }
+                done_res = true;
+                passes -= S;
+                first = false;
+                continue;
+            }
         }
         for (size_t ri = 0; ri < D->rs.size(); ri++) {
             RankState &R = D->rs[ri];
@@ -1006,14 +1078,14 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false)
             SlabLevel &sl = SL(D, D->rs[ri], l);
             k_restrict(sl.lv.g, sl.lv.f[MG3D_R], *tgt[ri].gc, tgt[ri].dc, s, tgt[ri].lo, tgt[ri].hi, !keep);
         }
-        /* u of this level is final until the prolongation on the way up: refresh its halos underneath the
-         * coarser levels */
-        CHK(start_u_exchange(D, MG3D_XK_HALO_U_DOWN, l));
         /* the coarser level starts from its right-hand side at once: only owned planes were produced */
         if (l - 1 < ld)
-            CHK(run_phase(D, (D->policy & 1) ? MG3D_XK_RHS_GATHER : MG3D_XK_RHS_ALLGATHER, ld - 1, s));
+            CHK(exchange(D, (D->policy & 1) ? MG3D_XK_RHS_GATHER : MG3D_XK_RHS_ALLGATHER, ld - 1, false));
         else
-            CHK(run_phase(D, MG3D_XK_HALO_D, l - 1, s));
+            CHK(exchange(D, MG3D_XK_HALO_D, l - 1, false));
+        /* u of this level is final until the prolongation on the way up: refresh its halos underneath the
+         * coarser levels (issued behind the right-hand side's exchange: one communicator, one in-order stream) */
+        CHK(start_u_exchange(D, MG3D_XK_HALO_U_DOWN, l));
     }
     /* ---- replicated levels: the ordinary V-cycle from level ld-1 (its guess zeroed first, :1258), on every rank -- or,
      * with MG3D_COARSE_GATHER=1, on rank 0 alone, whose correction is then broadcast (same bits either way: the ranks
@@ -1032,13 +1104,13 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false)
         }
     }
     if (D->policy & 1)
-        CHK(run_phase(D, MG3D_XK_CORR_BCAST, ld - 1, s));
+        CHK(exchange(D, MG3D_XK_CORR_BCAST, ld - 1, false));
     /* ---- up */
     for (int l = ld; l < L; l++) {
         /* :1331 on every local plane, halos included: the correction's halos (post-smoothed on owned +-1 only)
          * are refreshed first, those of u have been under way since the pre-smoother */
         if (l - 1 >= ld)
-            CHK(run_phase(D, MG3D_XK_HALO_U_UP, l - 1, s));
+            CHK(exchange(D, MG3D_XK_HALO_U_UP, l - 1, false));
         CHK(await_u(D, l));
         const int want = l == L - 1 ? 1 : 0;
         const bool fold = dist_split_up_leg(D, 1, want);
@@ -1106,7 +1178,7 @@ extern "C" int mg3d_dist_vcycles(mg3d_dist *D, int count, double *norms)
         dist_resolve_timers(D);
         /* an RCCL failure that surfaced asynchronously (a peer died, a transport error): an error here, not a hang or a
          * wrong number later */
-        for (ncclComm_t cm : {D->have_comm ? D->comm : nullptr, D->have_comm2 ? D->comm2 : nullptr})
+        for (ncclComm_t cm : {D->have_comm ? D->comm : nullptr})
             if (cm) {
                 ncclResult_t ae = ncclSuccess;
                 NCCLCHK(ncclCommGetAsyncError(cm, &ae));

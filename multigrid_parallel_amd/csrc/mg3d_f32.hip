@@ -779,6 +779,12 @@ extern "C" int mg3d32_destroy(mg3d32_ctx *ctx)
         if (l.alt)
             (void)hipFree(l.alt);
     }
+    for (auto &p : ctx->pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (hipEvent_t e : ctx->event_pool)
+        (void)hipEventDestroy(e);
     if (ctx->partials)
         (void)hipFree(ctx->partials);
     if (ctx->sumsq)
@@ -814,6 +820,9 @@ int mg3d32_create_slabs(int coarse_pts, int num_levels, int smooth_iters, double
     ctx->no_pairs = getenv("MG3D_F32_NO_PAIRS") && getenv("MG3D_F32_NO_PAIRS")[0] == '1';
     ctx->no_fuse = getenv("MG3D_F32_NO_FUSE") && getenv("MG3D_F32_NO_FUSE")[0] == '1';
     ctx->no_carry = getenv("MG3D_F32_NO_CARRY") && getenv("MG3D_F32_NO_CARRY")[0] == '1'; /* (creation: the only reads) */
+    ctx->timing = false;
+    for (auto &k : ctx->kt)
+        k.calls = 0, k.seconds = 0.;
     ctx->coarse64 = nullptr;
     ctx->partials = ctx->sumsq = ctx->h_sumsq = nullptr;
     ctx->stream = nullptr;
@@ -954,6 +963,83 @@ extern "C" int mg3d32_sync(mg3d32_ctx *ctx)
     return MG3D_OK;
 }
 
+/* ---------------------------------------------------------------------------------------- kernel timers */
+static const char *const kKernel32Names[MG3D32_NUM_KERNELS] = {"pair", "pair+tap", "prolong+pair", "prolong+pair+norm", "pair+norm",
+                                                               "residual+restrict", "residual", "prolong", "sweep1"};
+struct Scope32 { /* an event pair around the launches of one finest-level operator, when timing is on */
+    mg3d32_ctx *c;
+    int k;
+    hipEvent_t a;
+    Scope32(mg3d32_ctx *ctx, int level, int kernel) : c(ctx), k(kernel), a(nullptr)
+    {
+        if (!ctx->timing || level != ctx->L - 1)
+            return;
+        auto take = [&]() -> hipEvent_t {
+            if (!c->event_pool.empty()) {
+                hipEvent_t e = c->event_pool.back();
+                c->event_pool.pop_back();
+                return e;
+            }
+            hipEvent_t e = nullptr;
+            return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+        };
+        a = take();
+        if (a)
+            (void)hipEventRecord(a, c->stream);
+    }
+    ~Scope32()
+    {
+        if (!a)
+            return;
+        hipEvent_t b = nullptr;
+        if (!c->event_pool.empty()) {
+            b = c->event_pool.back();
+            c->event_pool.pop_back();
+        } else if (hipEventCreate(&b) != hipSuccess)
+            b = nullptr;
+        if (b) {
+            (void)hipEventRecord(b, c->stream);
+            c->pending.push_back({k, a, b});
+        } else {
+            c->event_pool.push_back(a);
+        }
+    }
+};
+static void resolve_timers32(mg3d32_ctx *ctx) /* behind a stream synchronisation */
+{
+    for (auto &p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->kt[p.k].calls++;
+            ctx->kt[p.k].seconds += ms * 1e-3;
+        }
+        ctx->event_pool.push_back(p.a);
+        ctx->event_pool.push_back(p.b);
+    }
+    ctx->pending.clear();
+}
+extern "C" const char *mg3d32_kernel_name(int k) { return k >= 0 && k < MG3D32_NUM_KERNELS ? kKernel32Names[k] : nullptr; }
+extern "C" int mg3d32_timing_enable(mg3d32_ctx *ctx, int on)
+{
+    if (!ctx)
+        return fail(MG3D_ERR_ARG, "mg3d32_timing_enable: NULL");
+    ctx->timing = on != 0;
+    if (on)
+        for (auto &k : ctx->kt)
+            k.calls = 0, k.seconds = 0.;
+    return MG3D_OK;
+}
+extern "C" int mg3d32_kernel_time_get(mg3d32_ctx *ctx, int kernel, int *launches, double *seconds)
+{
+    if (!ctx || kernel < 0 || kernel >= MG3D32_NUM_KERNELS)
+        return fail(MG3D_ERR_ARG, "mg3d32_kernel_time_get: bad arguments");
+    if (launches)
+        *launches = ctx->kt[kernel].calls;
+    if (seconds)
+        *seconds = ctx->kt[kernel].seconds;
+    return MG3D_OK;
+}
+
 /* ---------------------------------------------------------------------------------------- operators */
 static int chunk_for(int planes, long long blocks_per_plane, long long want = 4096)
 {
@@ -1002,6 +1088,8 @@ bool e32_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot, bool prolo
             const Geom gc = with_pro ? ctx->lv[level - 1].g : l.g;
             const float *ec = with_pro ? ctx->lv[level - 1].f[MG3D_U] : nullptr;
             double *part = (with_norm || with_tap) ? ctx->partials : nullptr;
+            Scope32 kt(ctx, level, with_tap ? MG3D32_K_PAIR_TAP : with_norm && with_pro ? MG3D32_K_PRO_PAIR_NORM : with_norm ? MG3D32_K_PAIR_NORM
+                                   : with_pro ? MG3D32_K_PRO_PAIR : MG3D32_K_PAIR);
 #define J2_LAUNCH(NORM, PRO, ...)                                                                                   \
     hipLaunchKernelGGL((jacobi32x2_kernel<NORM, PRO, ##__VA_ARGS__>), grid, block, 0, ctx->stream, l.g, l.f[MG3D_U], l.f[MG3D_D], \
                        l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, l.invHsq, part, ch, gc, ec, l.own_lo, l.own_hi)
@@ -1026,6 +1114,7 @@ bool e32_jacobi(mg3d32_ctx *ctx, int level, int iters, int norm_slot, bool prolo
         }
     }
     for (; it < iters; it++) {
+        Scope32 kt(ctx, level, MG3D32_K_SWEEP1);
         hipLaunchKernelGGL(jacobi32_kernel, dim3(gx, gy, (l.g.ni + chunk - 1) / chunk), dim3(64, 4, 1), 0, ctx->stream,
                            l.g, l.f[MG3D_U], l.f[MG3D_D], l.alt, l.hSq, 1.0f / 6.0f, ctx->omega, chunk);
         swap();
@@ -1051,6 +1140,7 @@ void e32_residual(mg3d32_ctx *ctx, int level, bool store, int slot)
     while ((long long)gx * gy * ((np + chunk - 1) / chunk) > MG3D_MAX_PARTIALS)
         chunk *= 2;
     const int gz = (np + chunk - 1) / chunk;
+    Scope32 kt(ctx, level, MG3D32_K_RESIDUAL);
     hipLaunchKernelGGL(residual32_kernel, dim3(gx, gy, gz), dim3(64, 4, 1), 0, ctx->stream, l.g, l.f[MG3D_U],
                        l.f[MG3D_D], l.invHsq, store ? l.f[MG3D_R] : nullptr, ctx->partials, chunk, p_lo, p_hi, l.own_lo,
                        l.own_hi);
@@ -1079,6 +1169,7 @@ void e32_residual_restrict(mg3d32_ctx *ctx, int level, int c_lo, int c_hi)
         int cch = 64; /* coarse planes per block */
         while (cch > 4 && (long long)px * py * ((nc + cch - 1) / cch) < 1024)
             cch /= 2;
+        Scope32 kt(ctx, level, MG3D32_K_RESIDUAL_RESTRICT);
         hipLaunchKernelGGL(residual_restrict32_kernel, dim3(px, py, (nc + cch - 1) / cch), dim3(64, J2_ROWS, 1), 0,
                            ctx->stream, lf.g, lf.f[MG3D_U], lf.f[MG3D_D], lf.invHsq, lc.g, lc.f[MG3D_D], cch, i_lo, i_hi);
     }
@@ -1092,6 +1183,7 @@ void e32_prolong(mg3d32_ctx *ctx, int level)
     Level32 &lf = ctx->lv[level], &lc = ctx->lv[level - 1];
     const int gx = ((lf.g.nk + 1) / 2 + 63) / 64, gy = ((lf.g.nj + 1) / 2 + 3) / 4;
     const int chunk = chunk_for(lf.g.ni, (long long)gx * gy, 2048);
+    Scope32 kt(ctx, level, MG3D32_K_PROLONG);
     hipLaunchKernelGGL(prolong32_kernel, dim3(gx, gy, (lf.g.ni + chunk - 1) / chunk), dim3(64, 4, 1), 0, ctx->stream,
                        lc.g, lc.f[MG3D_U], lf.g, lf.f[MG3D_U], chunk);
 }
@@ -1245,6 +1337,7 @@ extern "C" int mg3d32_vcycles(mg3d32_ctx *ctx, int count, double *norms)
         CHK(launch_ok32("mg3d32_vcycles"));
         HIPCHK(hipMemcpyAsync(ctx->h_sumsq, ctx->sumsq, nb * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        resolve_timers32(ctx);
         if (norms)
             for (int c = 0; c < nb; c++)
                 norms[done + c] = sqrt(ctx->h_sumsq[c]);

@@ -7,6 +7,19 @@
 
 #include "mg3d_ctx.h"
 
+enum { /* finest-level launches of the fp32 variant (mg3d32_kernel_name) */
+    MG3D32_K_PAIR = 0,       /* two sweeps in one launch */
+    MG3D32_K_PAIR_TAP,       /* ... with the previous cycle's residual norm tapped from the first sweep's sums */
+    MG3D32_K_PRO_PAIR,       /* prolongation + two sweeps */
+    MG3D32_K_PRO_PAIR_NORM,  /* prolongation + two sweeps + residual norm (third stage) */
+    MG3D32_K_PAIR_NORM,      /* two sweeps + residual norm */
+    MG3D32_K_RESIDUAL_RESTRICT, /* residual + full-weighting restriction, r never stored */
+    MG3D32_K_RESIDUAL,       /* residual (norm and / or store) */
+    MG3D32_K_PROLONG,        /* prolongation on its own */
+    MG3D32_K_SWEEP1,         /* one sweep per launch */
+    MG3D32_NUM_KERNELS
+};
+
 struct Level32 {
     Geom g; /* pitch and plane in floats; an i-slab has ni = owned + halo planes and ig0 = global index of plane 0 */
     double hd; /* spacing as the hierarchy defines it (double); h = (float)hd */
@@ -31,6 +44,19 @@ struct mg3d32_ctx {
     /* MG3D_F32_NO_PAIRS=1 / MG3D_F32_NO_FUSE=1, read when the context is created: one launch per sweep / per
      * operator instead of the paired and fused kernels (same bits; tests/test_gpu_f32.py) */
     bool no_pairs, no_fuse, no_carry; /* launch policy: the environment at creation, mg3d32_set_option afterwards */
+    /* kernel timers of the finest level's launches (mg3d32_timing_enable): hipEvent pairs recorded in-stream, resolved at
+     * the next host synchronisation the entry point does anyway */
+    bool timing;
+    struct KTime {
+        int calls;
+        double seconds;
+    } kt[MG3D32_NUM_KERNELS];
+    struct Pending32 {
+        int k;
+        hipEvent_t a, b;
+    };
+    std::vector<Pending32> pending;
+    std::vector<hipEvent_t> event_pool;
 };
 
 /* a context whose levels >= first_slab are i-slabs: owned global planes [glo[l], ghi[l]) plus `halo` planes on every

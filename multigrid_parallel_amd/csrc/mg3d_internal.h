@@ -111,12 +111,14 @@ int k_sweep(const mg3d_options &o, const Geom &g, const double *vin, const doubl
             const Geom *gce = nullptr, const double *ec = nullptr /* non-NULL: the input is vin + P(ec), the
             trilinear prolongation of the coarse field ec (smoothing-only launches, S = 2 or 4) */,
             int i_lo = -1, int i_hi = -1 /* local output planes of this launch; default all.  Several launches
-            with disjoint windows and the same vin/vout make up one sweep (overlap with halo exchange) */);
+            with disjoint windows and the same vin/vout make up one sweep (overlap with halo exchange) */,
+            int edge = 0 /* > 0: only the first and the last `edge` planes of [i_lo, i_hi), as one launch of two chunks (-1 when
+            the range is shorter than 2 * edge): the planes a halo exchange sends first, the interior in a second launch */);
 /* FOUR colour passes starting with colour c1 and, into partials, the residual norm of the state after the SECOND one
  * (the launch that ends one V-cycle -- its last two post-smoothing passes and its norm -- and begins the next: mg3d_ctx.hip,
  * "carried cycles").  Returns the number of partials written or -1. */
 int k_sweep_tap(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, double *partials, int max_partials,
-                double h, int c1, hipStream_t s, int acc_lo = 0, int acc_hi = -1, int i_lo = -1, int i_hi = -1);
+                double h, int c1, hipStream_t s, int acc_lo = 0, int acc_hi = -1, int i_lo = -1, int i_hi = -1, int edge = 0);
 /* One launch per leg of a V(2,2) cycle on a level (mg3d_sweep.hip, "one launch per leg").  down: S = 4 colour passes red
  * first, or S = 3 black first (behind another cycle), + residual + full-weighting restriction into the interior of dc;
  * partials (S = 3 only): sum of diff^2 of the INCOMING state over the colour the first pass updates.  up: the input is

@@ -115,6 +115,14 @@ static int launch_sweep(const mg3d_options &o, SweepArgs &a, int max_partials, h
     const int nout = a.i_hi - a.i_lo;
     const int ncu = device_cus();
     const long long T = (long long)a.ntj * a.ntk;
+    if (a.edge > 0) { /* the two end windows of the range as two chunks of one launch (see SweepArgs::edge) */
+        if (2 * a.edge > nout || (a.partials && 2 * T > max_partials))
+            return -1;
+        a.CI = a.edge;
+        a.xcd_remap = 2 * T < 64 ? 0 : 2 * T <= ncu ? 1 : 2;
+        hipLaunchKernelGGL((sweep_kernel<S, RES, RJ, NW, PF, PRO, RST, DP, TAP, C1K>), dim3((unsigned)(2 * T)), dim3(NW * WAVE), 0, s, a);
+        return (int)(2 * T);
+    }
     const int ovh = Sh::HI + Sh::ST + (RES == 2 ? 2 : 0) + 1;
     auto model_cost = [&](int ci) -> double { /* in steps; < 0: not launchable */
         const long long blocks = T * ((nout + ci - 1) / ci);
@@ -362,9 +370,10 @@ bool k_sweep_fuse_rst2(const mg3d_options &o, int N) /* two passes + residual + 
 static int sweep_impl(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
                       int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo, int acc_hi,
                       const Geom *gc, double *dc, int ic_lo, int ic_hi, const Geom *gce, const double *ec, int i_lo, int i_hi,
-                      bool tap)
+                      bool tap, int edge = 0)
 {
     SweepArgs a;
+    a.edge = edge;
     a.i_lo = i_lo >= 0 ? i_lo : 0;
     a.i_hi = i_hi >= 0 ? i_hi : g.ni;
     if (a.i_hi <= a.i_lo)
@@ -491,6 +500,7 @@ static void leg_args(SweepArgs &a, const Geom &g, const double *vin, const doubl
     a.gc = g;
     a.dc = nullptr;
     a.ic_lo = a.ic_hi = 0;
+    a.edge = 0;
 }
 
 int k_sweep_leg_down(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, const Geom &gc, double *dc, double h, int S,
@@ -532,15 +542,15 @@ int k_sweep_leg_up(const mg3d_options &o, const Geom &g, const double *vin, cons
 
 int k_sweep(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,
             int max_partials, double h, int S, int c1, bool residual, hipStream_t s, int acc_lo, int acc_hi,
-            const Geom *gc, double *dc, int ic_lo, int ic_hi, const Geom *gce, const double *ec, int i_lo, int i_hi)
+            const Geom *gc, double *dc, int ic_lo, int ic_hi, const Geom *gce, const double *ec, int i_lo, int i_hi, int edge)
 {
     return sweep_impl(o, g, vin, d, vout, r, partials, max_partials, h, S, c1, residual, s, acc_lo, acc_hi, gc, dc, ic_lo, ic_hi,
-                      gce, ec, i_lo, i_hi, false);
+                      gce, ec, i_lo, i_hi, false, edge);
 }
 
 int k_sweep_tap(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, double *partials, int max_partials,
-                double h, int c1, hipStream_t s, int acc_lo, int acc_hi, int i_lo, int i_hi)
+                double h, int c1, hipStream_t s, int acc_lo, int acc_hi, int i_lo, int i_hi, int edge)
 {
     return sweep_impl(o, g, vin, d, vout, nullptr, partials, max_partials, h, 4, c1, false, s, acc_lo, acc_hi, nullptr, nullptr,
-                      -1, -1, nullptr, nullptr, i_lo, i_hi, true);
+                      -1, -1, nullptr, nullptr, i_lo, i_hi, true, edge);
 }

@@ -22,6 +22,9 @@ struct SweepArgs {
     int vk, hk;     /* k-tiling: tile tk covers columns [vk*tk, vk*tk + 128) and owns those at least hk from its
                        edges (a tile edge on the global boundary needs no halo); vk = 128 - 2*hk */
     int CI;         /* planes per i-chunk (lock-step chunks: block -> (tile column, chunk), tile fastest) */
+    int edge;       /* > 0: this launch produces only the first and the last `edge` planes of [i_lo, i_hi) -- two chunks; the
+                       rest is another launch's (slab path: the planes a halo exchange sends are made first, the exchange
+                       then runs underneath the launch that makes the interior) */
     int i_lo, i_hi;     /* local output planes this launch produces */
     int acc_lo, acc_hi; /* local planes whose diff^2 enter the norm (owned planes of a slab) */
     /* fused prolongation (PRO): the level's input is vin + P(ec) (mg_3d.h:1000-1145); gce = geometry of ec */
@@ -231,8 +234,13 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
             tl = o + (tl - ((x - r0 + 8) & 7)) / 8;
         }
         t_lin = tl;
-        off = ch * a.CI;
-        len = min(a.CI, nout - off);
+        if (a.edge > 0) {
+            off = ch == 0 ? 0 : nout - a.edge;
+            len = a.edge;
+        } else {
+            off = ch * a.CI;
+            len = min(a.CI, nout - off);
+        }
     }
     double acc = 0.;
 

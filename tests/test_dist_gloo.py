@@ -149,13 +149,14 @@ def worker(r, P, port, c, L, nu, cycles, out_path, policy=0, carry=False):
                 dc = Hc.d[ld - 1].reshape(Ncr, Ncr, Ncr)
                 flo, fhi = owned(c, L, P, H, ld, r)
                 S.restrict_planes(sl.r, sl.ig0, sl.N, dc, 0, Ncr, 0 if r == 0 else flo // 2, Ncr if r == P - 1 else fhi // 2)
-            # u of this level is final until the way up: its halos travel now (on the GPU: underneath the
-            # coarser levels, on the communication stream)
-            plan.run(PL.HALO_U_DOWN, l, array_of)
+            # first what the coarser level waits for ...
             if l - 1 >= ld:
                 plan.run(PL.HALO_D, l - 1, array_of)
             else:
                 plan.run(PL.RHS_GATHER if policy else PL.RHS_ALLGATHER, ld - 1, array_of)
+            # ... then the halos of u, final on this level until the way up (on the GPU: issued behind the exchange above on
+            # the one communication stream, running underneath the coarser levels)
+            plan.run(PL.HALO_U_DOWN, l, array_of)
         # ---- coarse levels: identical on every rank -- or on rank 0 alone, whose correction is then broadcast
         if not policy or r == 0:
             Hc.u[ld - 1][:] = 0.0

@@ -47,8 +47,9 @@ def test_every_send_has_its_receive(c, L, nu, P, overlap, policy):
         kinds = {(e.kind, e.level, e.stream) for es in per for e in es}
         assert len(kinds) == 1, f"phase {ph}: all ranks agree on what it is and on which stream it runs"
         kind, level, stream = kinds.pop()
-        assert stream in (0, 1) and (stream == 0 or overlap == 1)
-        assert stream == (overlap if kind in (PL.HALO_U_DOWN, PL.HALO_U_NEXT) else 0)
+        # overlap off: everything on the compute stream (0).  On: everything on the communication stream with the one
+        # communicator -- 2 = overlapped (the u halos), 1 = the compute stream joins at once (critical path)
+        assert stream == ((2 if kind in (PL.HALO_U_DOWN, PL.HALO_U_NEXT) else 1) if overlap else 0)
         for r in range(P):
             for e in per[r]:
                 assert e.count > 0 and e.plane_elems > 0
@@ -102,8 +103,10 @@ def test_every_send_has_its_receive(c, L, nu, P, overlap, policy):
 
 @pytest.mark.parametrize("c,L,nu,P", [(9, 7, 2, 8), (5, 6, 3, 3)])
 def test_phase_sequence_of_a_cycle(c, L, nu, P):
-    """the order dist_enqueue_vcycle walks: per distributed level u (for the way up), then the coarser right-hand side;
-    the coarse levels; per level the correction's halos; the finest u for the next cycle; the norm"""
+    """the order dist_enqueue_vcycle walks: per distributed level the coarser right-hand side (what the next level waits
+    for), then the level's u halos (for the way up: they travel underneath the coarser levels -- one communicator, one
+    in-order stream, so the critical exchange is issued first); the coarse levels; per level the correction's halos; the
+    finest u for the next cycle; the norm"""
     lib = M.lib()
     H = lib.mg3d_slab_halo(nu)
     ld = lib.mg3d_slab_first_level(c, L, P, H)
@@ -113,8 +116,8 @@ def test_phase_sequence_of_a_cycle(c, L, nu, P):
             seq.append((e.phase, e.kind, e.level))
     want = []
     for l in range(L - 1, ld - 1, -1):
-        want.append((PL.HALO_U_DOWN, l))
         want.append((PL.HALO_D, l - 1) if l - 1 >= ld else (PL.RHS_ALLGATHER, ld - 1))
+        want.append((PL.HALO_U_DOWN, l))
     for l in range(ld + 1, L):
         want.append((PL.HALO_U_UP, l - 1))
     want.append((PL.HALO_U_NEXT, L - 1))

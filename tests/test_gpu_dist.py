@@ -5,8 +5,17 @@ itself bit-identical to the oracle, tests/test_gpu_parity.py)."""
 import numpy as np
 import pytest
 
+import _oracle as O
 import multigrid_parallel_amd as M
 from multigrid_parallel_amd.binding import MG3D_D, MG3D_R, MG3D_U
+
+EXACT_NORM_RTOL = 1e-13  # the slab path's reduction (per-rank partial sums, all-gather, sum in rank order) against the exactly rounded sum
+
+
+def exact_norm(d, L):
+    """exactly rounded residual norm of the assembled finest-level state of a DistSolver (tests/_oracle.py)"""
+    N = d.N
+    return O.exact_residual_norm(d.download(MG3D_U, L - 1), d.download(MG3D_D, L - 1), N, d.h)
 
 pytestmark = pytest.mark.gpu
 
@@ -33,6 +42,7 @@ def test_slab_vcycles_match_single_domain(monkeypatch, c, L, nu, P, min_planes):
         d.setup_test_problem()
         norms = d.vcycles(cycles)
         u = d.download(MG3D_U, L - 1)
+        assert norms[-1] == pytest.approx(exact_norm(d, L), rel=EXACT_NORM_RTOL)
     assert np.array_equal(u, want_u)
     np.testing.assert_allclose(norms, want_norms, rtol=1e-11, atol=0)
 
@@ -54,6 +64,7 @@ def test_slab_carried_cycles(monkeypatch, c, L, P, min_planes):
             d.setup_test_problem()
             norms = list(d.vcycles(4)) + list(d.vcycles(1)) + list(d.vcycles(2))
             assert d.carried_cycles() == (4 if flag == "0" else 0)  # 3 + 0 + 1
+            assert norms[-1] == pytest.approx(exact_norm(d, L), rel=EXACT_NORM_RTOL)
             res.append((np.array(norms), d.download(MG3D_U, L - 1), [d.download(MG3D_U, l) for l in range(d.first_level, L - 1)]))
     assert np.array_equal(res[0][1], want_u) and np.array_equal(res[1][1], want_u)
     for a, b in zip(res[0][2], res[1][2]):
@@ -110,31 +121,33 @@ def test_single_rank_rccl_communicator():
 
 
 def test_single_rank_builds_real_communicators(monkeypatch):
-    """MG3D_FORCE_COMM=1: the 128-byte unique id travels through ctypes into ncclCommInitRank, the second
-    communicator comes from ncclCommSplit, both are destroyed again -- everything of the multi-process set-up that
-    one GPU can run (RCCL refuses two ranks on one device)."""
+    """MG3D_FORCE_COMM=1: the 128-byte unique id travels through ctypes into ncclCommInitRank, every exchange of the cycle
+    runs as a self-addressed grouped send/receive (and the norm as a real all-gather) on the ONE communicator, driven from
+    the communication stream behind events of the compute stream (round 4: the default for RCCL too), and the communicator
+    is destroyed again -- everything of the multi-process set-up that one GPU can run (RCCL refuses two ranks on one
+    device)."""
     monkeypatch.setenv("MG3D_FORCE_COMM", "1")
-    monkeypatch.setenv("MG3D_OVERLAP", "1")  # opt-in for the RCCL transport: second stream + ncclCommSplit communicator
     uid = M.DistSolver.unique_id()
     assert len(uid) == 128 and any(uid)
     want_norms, want_u = single(5, 4, 2, 3)
     with M.DistSolver(5, 4, 2, rank=0, nranks=1, unique_id=uid) as d:
-        assert d.comm_info()[:2] == (1, True)  # ncclCommCount of the real communicator; overlap opted in
+        assert d.comm_info()[:2] == (1, True)  # ncclCommCount of the real communicator; exchanges on the communication stream
         d.setup_test_problem()
         norms = d.vcycles(3)
         assert np.array_equal(d.download(MG3D_U, 3), want_u)
     np.testing.assert_allclose(norms, want_norms, rtol=1e-11)
-    monkeypatch.delenv("MG3D_OVERLAP")
+    monkeypatch.setenv("MG3D_NO_OVERLAP", "1")
     uid = M.DistSolver.unique_id()  # a unique id serves one communicator
-    with M.DistSolver(5, 4, 2, rank=0, nranks=1, unique_id=uid) as d:  # the RCCL default: one communicator, no overlap
+    with M.DistSolver(5, 4, 2, rank=0, nranks=1, unique_id=uid) as d:  # every exchange on the compute stream
         assert d.comm_info()[:2] == (1, False)
         d.setup_test_problem()
         assert np.array_equal(d.vcycles(3), norms)
 
 
 def test_overlap_and_sequential_exchange_agree(monkeypatch):
-    """MG3D_NO_OVERLAP=1 keeps every halo exchange on the compute stream; by default the large u exchanges run on
-    a second stream underneath the coarser levels and the norm kernel."""
+    """MG3D_NO_OVERLAP=1 keeps every halo exchange on the compute stream; by default all of them are issued on the
+    communication stream (one communicator) and the large u exchanges run underneath the coarser levels, the norm kernel
+    and the interior of the launch that follows them."""
     for carry_min in ("130", "66"):  # plain schedule / carried cycles (whose last u exchange is the three-plane one)
         monkeypatch.setenv("MG3D_CARRY_MIN", carry_min)
         res = []
@@ -144,7 +157,9 @@ def test_overlap_and_sequential_exchange_agree(monkeypatch):
                 d.setup_test_problem()
                 res.append((d.vcycles(5), d.download(MG3D_U, 4)))
                 assert d.carried_cycles() == (4 if carry_min == "66" else 0)
-        assert np.array_equal(res[0][0], res[1][0])
+        # (with the exchanges on the communication stream the stage's last launch makes its edge windows first, as a launch of
+        # their own: the same squares in another grouping of per-block partial sums)
+        np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-13)
         assert np.array_equal(res[0][1], res[1][1])
 
 

@@ -51,6 +51,9 @@ def test_configs3_513_cubed_on_slabs(P):
         d.setup_test_problem()
         norms = d.vcycles(2)
         u = d.download(MG3D_U, 6)
+        if P == 8:  # the slab path's own reduction at full size against the exactly rounded sum of the same 133 M squares
+            import _oracle as O
+            assert norms[-1] == pytest.approx(O.exact_residual_norm(u, d.download(MG3D_D, 6), 513, d.h), rel=1e-13)
     assert np.array_equal(u, want["u"])
     np.testing.assert_allclose(norms, want["norms"], rtol=norm_rtol(513), atol=0)
     np.testing.assert_allclose(norms, [3.86147e+07, 4.68671e+06], rtol=2e-6)  # the reference's printed history

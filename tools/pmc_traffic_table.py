@@ -3,14 +3,15 @@
 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum.  Per kernel name the dispatch group with the largest traffic (= the finest
 level) is averaged.  gfx950 correction: read bytes = 2 x FETCH_SIZE for 16-byte-per-lane loads (see the header of
 profiles/r01_pmc_traffic_finest_level.txt).  Usage: pmc_traffic_table.py <dirA> <dirB>"""
-import csv, sys
+import csv, glob, os, sys
 from collections import defaultdict
 
 
 def load(d):
     acc = defaultdict(lambda: defaultdict(list))  # kernel -> grid -> counter -> values
-    for row in csv.DictReader(open(d + "/p_counter_collection.csv")):
-        acc[row["Kernel_Name"]][(int(row["Grid_Size_X"]) if "Grid_Size_X" in row else int(row["Grid_Size"]), row["Counter_Name"])].append(float(row["Counter_Value"]))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):  # (rocprofv3 nests a host-name directory)
+        for row in csv.DictReader(open(f)):
+            acc[row["Kernel_Name"]][(int(row["Grid_Size_X"]) if "Grid_Size_X" in row else int(row["Grid_Size"]), row["Counter_Name"])].append(float(row["Counter_Value"]))
     return acc
 
 

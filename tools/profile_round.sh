@@ -4,7 +4,8 @@
 tag=${1:-r02}
 out=gpurun_out/prof_$tag
 mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+[ -n "$GRAFT_REPO_ROOT" ] && [ -d "$GRAFT_REPO_ROOT" ] || { echo "profile_round.sh: GRAFT_REPO_ROOT is not set (run this through gpurun)"; exit 2; }
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 2
 # the counter passes first: bench.py reads profiles/pmc_traffic.json and drops it when the kernel sources changed since
 python3 tools/pmc_traffic.py $tag > $out/pmc_traffic.log 2>&1
 cp gpurun_out/pmc_traffic.json gpurun_out/${tag}_pmc_traffic_finest_level.txt $out/ 2>/dev/null
