@@ -325,6 +325,8 @@ def main():
     ap.add_argument("--cpu-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--breakdown", action="store_true", help="print the per-level stage table to stderr")
     ap.add_argument("--timing-mode", type=int, default=6, help=argparse.SUPPRESS)  # A/B of the timer cost (0 = none)
+    ap.add_argument("--no-alt-schedules", action="store_true",
+                    help="skip the two extra timed regions (option carry = 0, option legs = 1) reported beside `value`")
     ap.add_argument("--f32", action="store_true",
                     help="BASELINE configs[4] on one GPU instead of the headline: fp32, damped Jacobi, F-cycle start "
                          "(parity unpinned); default size 9 8 2 = 1025^3")
@@ -500,7 +502,7 @@ def main():
     # the same K cycles with every cycle run on its own (MG3D_NO_CARRY=1: no launch shared between consecutive cycles,
     # csrc/mg3d_ctx.hip "carried cycles"), no timers: reported beside `value`; both schedules give the same bits
     plain = legs = None
-    if world == 1:
+    if world == 1 and not args.no_alt_schedules:
         def timed_with(key, value, what):
             old = solver.get_option(key)
             solver.set_option(key, value)  # the options API (mg3d_ctx_set_option): no environment on any launch path

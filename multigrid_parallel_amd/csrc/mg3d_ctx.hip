@@ -1004,7 +1004,10 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out)
     double *const part_a = ctx->partials, *const part_b = ctx->partials + MG3D_MAX_PARTIALS / 2;
     for (int l = q; l >= 1; l--) {
         Level &lev = ctx->lv[l];
-        if (l == q && can_legs) {
+        /* (a cycle with no cycle in front of it takes the ordinary down-leg below -- four passes, then residual +
+         * restriction: the one-launch form of THAT leg needs a six-plane window, spills 180 bytes at eight rows per thread
+         * and took 2.1 ms against 0.66 + 0.49: profiles/r04_bench_kernel_stats_note.txt) */
+        if (l == q && can_legs && legs_in != 0) {
             Level &lc = ctx->lv[l - 1];
             {
                 StageScope t(ctx, l, MG3D_ST_SMOOTH1);
@@ -1018,16 +1021,15 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out)
                 } else {
                     StageScope kt(ctx, l, MG3D_K_LEG_DOWN, true);
                     /* behind another cycle: black, red, black (the first red pass is the identity) and the black half of
-                     * that cycle's norm; else the four passes of :1282.  + residual + restriction (:1294 + :1310) */
+                     * that cycle's norm, + residual + restriction (:1282 + :1294 + :1310) */
                     const int np = k_sweep_leg_down(ctx->opt, lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, lc.g, lc.f[MG3D_D], lev.h,
-                                                    legs_in == 2 ? 3 : 4, legs_in == 2 ? part_b : nullptr, MG3D_MAX_PARTIALS / 2, s);
+                                                    3, part_b, MG3D_MAX_PARTIALS / 2, s);
                     if (np < 0)
                         return fail(MG3D_ERR_STATE, "one launch per leg: no kernel for the down-leg");
                     double *t2 = lev.f[MG3D_U];
                     lev.f[MG3D_U] = lev.alt;
                     lev.alt = t2;
-                    if (legs_in == 2)
-                        k_fold2(part_a, ctx->legs_npa, part_b, np, ctx->sumsq + ctx->legs_slot, s);
+                    k_fold2(part_a, ctx->legs_npa, part_b, np, ctx->sumsq + ctx->legs_slot, s);
                 }
             }
             { StageScope t(ctx, l, MG3D_ST_RESIDUAL1); }

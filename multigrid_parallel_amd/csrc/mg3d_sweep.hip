@@ -460,9 +460,10 @@ static int sweep_impl(const mg3d_options &o, const Geom &g, const double *vin, c
  * through the chip twice per cycle instead of three or four times.  The windows are five to six planes deep: they fit at
  * one wave per SIMD (eight rows per thread, 256 threads, the 512-register budget) with the oldest slots of the d window
  * parked in LDS (DP).
- *   down: S colour passes starting with colour c1 (4: red first, mg_3d.h:657; 3: black first -- the cycle's first red
- *         pass is the identity behind the previous cycle's last red pass), the residual (:1294) and its full-weighting
- *         restriction into the interior of the coarse right-hand side (:1310).  partials != NULL (S = 3 only): the sum of
+ *   down: S = 3 colour passes, black first -- the cycle's first red pass (mg_3d.h:657) is the identity behind the previous
+ *         cycle's last red pass --, the residual (:1294) and its full-weighting restriction into the interior of the
+ *         coarse right-hand side (:1310).  (S = 4, the leg of a cycle with none in front of it, needs a six-plane window:
+ *         180 bytes of scratch, 2.1 ms at 513^3 against 0.66 + 0.49 as two launches -- not instantiated.)  partials != NULL: the sum of
  *         diff^2 of the INCOMING state over the colour the first pass updates -- the second half of the previous cycle's
  *         residual norm (:1354), see k_sweep_leg_up.
  *   up:   prolongation (:1331) folded into the loads, four post-smoothing passes black, red, black, red (:1341).
@@ -473,9 +474,6 @@ static int sweep_impl(const mg3d_options &o, const Geom &g, const double *vin, c
 #endif
 #ifndef MG3D_LEG_DP_DOWN3
 #define MG3D_LEG_DP_DOWN3 2
-#endif
-#ifndef MG3D_LEG_DP_DOWN4
-#define MG3D_LEG_DP_DOWN4 1
 #endif
 
 static void leg_args(SweepArgs &a, const Geom &g, const double *vin, const double *d, double *vout, double *partials, double h,
@@ -515,8 +513,6 @@ int k_sweep_leg_down(const mg3d_options &o, const Geom &g, const double *vin, co
     a.dc = dc;
     a.ic_lo = ic_lo >= 0 ? ic_lo : 0;
     a.ic_hi = ic_hi >= 0 ? ic_hi : gc.ni;
-    if (S == 4 && !partials)
-        return launch_sweep<4, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN4, -1>(o, a, max_partials, s);
     if (S == 3 && partials)
         return launch_sweep<3, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN3, 0>(o, a, max_partials, s);
     if (S == 3)

@@ -52,7 +52,6 @@ def test_configs3_513_cubed_on_slabs(P):
         norms = d.vcycles(2)
         u = d.download(MG3D_U, 6)
         if P == 8:  # the slab path's own reduction at full size against the exactly rounded sum of the same 133 M squares
-            import _oracle as O
             assert norms[-1] == pytest.approx(O.exact_residual_norm(u, d.download(MG3D_D, 6), 513, d.h), rel=1e-13)
     assert np.array_equal(u, want["u"])
     np.testing.assert_allclose(norms, want["norms"], rtol=norm_rtol(513), atol=0)

@@ -10,7 +10,7 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
 # a cycle ends with the fold of the norm's partial sums
-ends = [i for i, r in enumerate(rows) if name(r).startswith("fold_partials")]
+ends = [i for i, r in enumerate(rows) if name(r).startswith("fold_partials") or name(r).startswith("fold2_partials")]
 lo, hi = ends[-back - 1] + 1, ends[-back] + 1
 t_prev = int(rows[lo - 1]["End_Timestamp"])
 t0 = t_prev
