@@ -161,6 +161,9 @@ __device__ __forceinline__ void st_stream(double *p, double2 o)
 #ifndef MG3D_KERNEL_ATTR
 #define MG3D_KERNEL_ATTR
 #endif
+#ifndef MG3D_STAGE_MAJOR
+#define MG3D_STAGE_MAJOR 1 /* rows of a one-wave-per-SIMD thread whose stage chains are interleaved in the source (1: row-major).  Same-box A/B at 513^3, round 4: 1 -> 2.450, 2 -> 2.466, 4 -> 2.811 ms per cycle (the scheduler re-orders either way; wider groups only add AGPR traffic) */
+#endif
 template <int S, int RES, int RJ, int NW, int PF, bool PRO, bool RST, int DP, int TAP, int C1K = -1>
 __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepArgs a)
 {
@@ -575,6 +578,35 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
             }
         }
 
+        /* DP > 0, MG3D_DP_PREFETCH: the parked d values this step's stages read, requested HERE -- a step's worth of LDS
+         * latency ahead of their first use -- instead of one ds_read in front of the multiply that needs it (24
+         * `s_waitcnt lgkmcnt(0)` a step in the listing, each right behind its read).  The scheduling barrier keeps the
+         * compiler from sinking them back.  Measured: no gain (see the switch). */
+#ifndef MG3D_DP_PREFETCH
+#define MG3D_DP_PREFETCH 0 /* same-box A/B at 513^3 (round 4): up-leg 0.872-0.882 ms with, 0.866-0.877 without; the down-leg spills
+                            * 44-72 bytes with it (1.02 / 1.15 ms for one / both slots ahead against 1.03): the waits the listing
+                            * shows are not where the time goes (tools/ilp_probe.hip: a dependent fp64 add costs what an
+                            * independent one does; the SQ counters put 42 % of the wave's cycles into VALU issue, 8 % into scalar
+                            * issue, 29 % into waiting to issue).  Off; kept as the record of the experiment. */
+#endif
+        /* (the restricting down-leg sits at the 512-register limit: with both of its parked slots requested ahead it spills
+         * 72 bytes; it requests DPF of them ahead and reads the rest where they are used) */
+#ifndef MG3D_DP_PREFETCH_RST
+#define MG3D_DP_PREFETCH_RST 0
+#endif
+        constexpr int DPF = MG3D_DP_PREFETCH == 0 ? 0 : RES == 2 ? (MG3D_DP_PREFETCH_RST < DP ? MG3D_DP_PREFETCH_RST : DP) : DP;
+        double ddp[RJ][DPF > 0 ? DPF : 1];
+        if constexpr (DPF > 0) {
+#pragma unroll
+            for (int m = 0; m < DPF; m++) {
+                int idx = ring + (DP - 1 - m); /* slot KV + m was parked at the end of step pl - 1 - m: ring slot (pl - 1 - m) mod DP */
+                idx -= idx >= DP ? DP : 0;
+#pragma unroll
+                for (int rr = 0; rr < RJ; rr++)
+                    ddp[rr][m] = dpk[idx][w * RJ + rr][(PAR + rr) & 1][lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         /* rows of the neighbouring waves, written at the end of the previous step */
         double e_top[STX], e_bot[STX];
 #pragma unroll
@@ -671,137 +703,164 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
                 }
             }
         }
+        /* The rows' stage chains.  ROW-major (every stage of a row, then the next row) is the order the two-waves-per-SIMD
+         * shapes were tuned in: the other wave fills the gaps of a dependent chain.  The one-wave-per-SIMD shapes (eight rows a
+         * thread) run STAGE-major -- stage s of all eight rows, then stage s + 1: consecutive instructions then belong to
+         * independent rows, where row-major issued five dependent fp64 adds back to back with nobody to hide their latency
+         * behind (SQ counters of the one-launch legs, round 4: 25 % of the wave's cycles issue stalls, 22 % waits). */
+        constexpr int ILV = (NW == 4 && RJ == 8 && RJ % MG3D_STAGE_MAJOR == 0) ? MG3D_STAGE_MAJOR : 1;
+        /* ILV rows at a time, stage-major inside the group (no lambdas: wrapping the bodies into closures made the tapped
+         * four-pass shape -- 241 VGPRs -- spill 44 bytes) */
 #pragma unroll
-        for (int rr = 0; rr < RJ; rr++) {
-            const int X = (PAR + rr) & 1; /* active column of this row at this step */
-            double nw[STX + 1];
-            nw[0] = X ? cur_v[rr].y : cur_v[rr].x;
-            double diffs[2] = {0., 0.};
+        for (int r0 = 0; r0 < RJ; r0 += ILV) {
+            double nwG[ILV][STX + 1], diffsG[ILV][2];
+#pragma unroll
+            for (int g = 0; g < ILV; g++) {
+                const int X = (PAR + r0 + g) & 1;
+                nwG[g][0] = X ? cur_v[r0 + g].y : cur_v[r0 + g].x;
+                diffsG[g][0] = diffsG[g][1] = 0.;
+            }
 #pragma unroll
             for (int s = 1; s <= ST; s++) {
-                const double up = last[rr][s - 1][X]; /* plane q-1: two steps old */
-                const double dn = nw[s - 1];          /* plane q+1: this step */
-                const double jm = (rr > 0) ? last[rr - 1][s - 1][X] : e_top[s - 1];
-                const double jp = (rr < RJ - 1) ? last[rr + 1][s - 1][X] : e_bot[s - 1];
-                double km, kp;
-                if (X == 0) {
-                    km = lane_from_left(last[rr][s - 1][1]);
-                    kp = last[rr][s - 1][1];
-                } else {
-                    km = last[rr][s - 1][0];
-                    kp = lane_from_right(last[rr][s - 1][0]);
+#pragma unroll
+                for (int g = 0; g < ILV; g++) {
+                    const int rr = r0 + g;
+                    const int X = (PAR + rr) & 1; /* active column of this row at this step */
+                        const double up = last[rr][s - 1][X]; /* plane q-1: two steps old */
+                        const double dn = nwG[g][s - 1];          /* plane q+1: this step */
+                        const double jm = (rr > 0) ? last[rr - 1][s - 1][X] : e_top[s - 1];
+                        const double jp = (rr < RJ - 1) ? last[rr + 1][s - 1][X] : e_bot[s - 1];
+                        double km, kp;
+                        if (X == 0) {
+                            km = lane_from_left(last[rr][s - 1][1]);
+                            kp = last[rr][s - 1][1];
+                        } else {
+                            km = last[rr][s - 1][0];
+                            kp = lane_from_right(last[rr][s - 1][0]);
+                        }
+                        double dd; /* DLAG: slot 0 = plane i - 1 (load_plane) */
+                        if constexpr (DP > 0) {
+                            if (s - 1 < KV) {
+                                dd = dring[rr][s - 1][X];
+                            } else {
+                                /* slot KV + m was parked at the end of step pl - 1 - m, into ring slot (pl - 1 - m) mod DP */
+                                const int m = s - 1 - KV; /* compile-time after unrolling */
+                                if (m < DPF) { /* (compile time) */
+                                    dd = ddp[rr][m < DPF ? m : 0];
+                                } else {
+                                    int idx = ring + (DP - 1 - m);
+                                    idx -= idx >= DP ? DP : 0;
+                                    dd = dpk[idx][w * RJ + rr][X][lane];
+                                }
+                            }
+                        } else {
+                            dd = dring[rr][s - DLAG][X];
+                        }
+                        const double center = (s == 1) ? in_prev[rr][X] : last[rr][s - 2][X];
+                        double sum = up + dn;
+                        sum = sum + jm;
+                        sum = sum + jp;
+                        sum = sum + km;
+                        sum = sum + kp;
+                        /* `&`, not `&&`: a short-circuit on the wave-uniform part turns every update into a scalar branch around
+                         * it (78 branches a step); the select costs nothing and leaves one basic block to schedule */
+                        const bool updu = row_upd[rr] & pl_upd[s]; /* wave-uniform part of "this point is updated" */
+                        if (s <= S) {
+        #ifdef MG3D_EXPERIMENT_DROP_FLOPS /* timing experiment only (wrong results): is the step bound by its fp64 operations? */
+                            const double val = sum - dd;
+        #else
+                            const double val = a.sixth * (sum - a.hSq * dd); /* mg_3d.h:438-443 */
+        #endif
+                            nwG[g][s] = (updu & col_upd[X]) ? val : center;
+                            if constexpr (HASTAP) {
+                                /* The tap: the residual norm of the state BETWEEN pass TAPQ and pass TAPQ + 1 without a stage of its
+                                 * own.  The colour pass TAPQ has just updated: its residual uses that pass's neighbour sum (as
+                                 * below).  The other colour: pass TAPQ + 1 is about to update it from exactly the six neighbours
+                                 * (all of the colour pass TAPQ + 1 leaves alone) and the centre (untouched by pass TAPQ) that the
+                                 * residual of the tapped state is made of -- mg_3d.h:819-821 on the sum the update forms anyway.
+                                 * TAPQ = S has only the first half, TAPQ = 0 only the second: two launches, one norm. */
+                                if (s == TAPQ || s == TAPQ + 1) {
+                                    const double diff = dd - a.invHsq * (sum - 6 * (s == TAPQ ? nwG[g][s] : center));
+                                    if ((updu & row_own[rr]) & acc_ok[s])
+                                        acc += own_upd[X] ? diff * diff : 0.;
+                                }
+                            }
+                            if ((RES == 1 || RES == 2) && s == S) { /* residual of the point just updated: same six neighbours */
+                                const double diff = dd - a.invHsq * (sum - 6 * nwG[g][s]); /* mg_3d.h:819-821 */
+                                diffsG[g][0] = diff;
+                                /* adding +0 leaves a sum of squares unchanged: a select, not a branch */
+                                if constexpr (RES == 1)
+                                    if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
+                                        acc += own_upd[X] ? diff * diff : 0.;
+                            }
+                        } else {
+                            const double diff = dd - a.invHsq * (sum - 6 * center); /* mg_3d.h:819-821 */
+                            nwG[g][s] = center;
+                            diffsG[g][S > 0 ? 1 : s - 1] = diff;
+                            if constexpr (RES == 1)
+                                if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
+                                    acc += own_upd[X] ? diff * diff : 0.;
+                        }
+
                 }
-                double dd; /* DLAG: slot 0 = plane i - 1 (load_plane) */
-                if constexpr (DP > 0) {
-                    if (s - 1 < KV) {
-                        dd = dring[rr][s - 1][X];
-                    } else {
-                        /* slot KV + m was parked at the end of step pl - 1 - m, into ring slot (pl - 1 - m) mod DP */
-                        const int m = s - 1 - KV; /* compile-time after unrolling */
-                        int idx = ring + (DP - 1 - m);
-                        idx -= idx >= DP ? DP : 0;
-                        dd = dpk[idx][w * RJ + rr][X][lane];
+            }
+#pragma unroll
+            for (int g = 0; g < ILV; g++) {
+                const int rr = r0 + g;
+                const int X = (PAR + rr) & 1;
+                /* ---- stores: v' of plane i-S, r of plane i-S-2 (pairs complete at this step) */
+                if constexpr (S > 0) {
+                    if (MG3D_AND(v_ok, row_own[rr])) { /* wave-uniform */
+                        const double other = last[rr][S - 1][X ^ 1]; /* finished one step ago */
+                        double2 o;
+                        o.x = X ? other : nwG[g][S];
+                        o.y = X ? nwG[g][S] : other;
+                        if (pair_own)
+                            st_stream(voutb + lane_off(row_off[rr]), o);
                     }
-                } else {
-                    dd = dring[rr][s - DLAG][X];
                 }
-                const double center = (s == 1) ? in_prev[rr][X] : last[rr][s - 2][X];
-                double sum = up + dn;
-                sum = sum + jm;
-                sum = sum + jp;
-                sum = sum + km;
-                sum = sum + kp;
-                /* `&`, not `&&`: a short-circuit on the wave-uniform part turns every update into a scalar branch around
-                 * it (78 branches a step); the select costs nothing and leaves one basic block to schedule */
-                const bool updu = row_upd[rr] & pl_upd[s]; /* wave-uniform part of "this point is updated" */
-                if (s <= S) {
-#ifdef MG3D_EXPERIMENT_DROP_FLOPS /* timing experiment only (wrong results): is the step bound by its fp64 operations? */
-                    const double val = sum - dd;
-#else
-                    const double val = a.sixth * (sum - a.hSq * dd); /* mg_3d.h:438-443 */
-#endif
-                    nw[s] = (updu & col_upd[X]) ? val : center;
-                    if constexpr (HASTAP) {
-                        /* The tap: the residual norm of the state BETWEEN pass TAPQ and pass TAPQ + 1 without a stage of its
-                         * own.  The colour pass TAPQ has just updated: its residual uses that pass's neighbour sum (as
-                         * below).  The other colour: pass TAPQ + 1 is about to update it from exactly the six neighbours
-                         * (all of the colour pass TAPQ + 1 leaves alone) and the centre (untouched by pass TAPQ) that the
-                         * residual of the tapped state is made of -- mg_3d.h:819-821 on the sum the update forms anyway.
-                         * TAPQ = S has only the first half, TAPQ = 0 only the second: two launches, one norm. */
-                        if (s == TAPQ || s == TAPQ + 1) {
-                            const double diff = dd - a.invHsq * (sum - 6 * (s == TAPQ ? nw[s] : center));
-                            if ((updu & row_own[rr]) & acc_ok[s])
-                                acc += own_upd[X] ? diff * diff : 0.;
+                if constexpr (RES == 2 || (RES == 1 && RST)) { /* RST = false: the norm only, r is not assembled */
+                    /* column X: the residual-only stage now; column X^1: the previous step's diff */
+                    double2 o;
+                    const double kept = RPARK ? rkpark[w * RJ + rr][lane] : rkeep[rr];
+                    o.x = X ? kept : diffsG[g][1];
+                    o.y = X ? diffsG[g][1] : kept;
+                    if constexpr (RES == 2) { /* read by the NEXT step's restriction */
+                        if constexpr (RPARK)
+                            rpark[w * RJ + rr][lane] = o;
+                        else
+                            rlag[rr] = o;
+                        if (rr == (CO == 0 ? RJ - 1 : 0))
+                            rex[par][w][lane] = o;
+                    }
+                    if (RES == 1 && MG3D_AND(MG3D_AND(r_ok, row_own[rr]), row_upd[rr])) { /* wave-uniform */
+                        double MG3D_GLOBAL *dst = reinterpret_cast<double MG3D_GLOBAL *>(routb + lane_off(row_off[rr]));
+                        if (own_both) {
+                            v2d x;
+                            x.x = o.x;
+                            x.y = o.y;
+                            *reinterpret_cast<v2d MG3D_GLOBAL *>(dst) = x;
+                        }
+                        if (k_edge_tile) { /* boundary entries of r are never written (mg_3d.h:824-825) */
+                            if (own_only0)
+                                dst[0] = o.x;
+                            if (own_only1)
+                                dst[1] = o.y;
                         }
                     }
-                    if ((RES == 1 || RES == 2) && s == S) { /* residual of the point just updated: same six neighbours */
-                        const double diff = dd - a.invHsq * (sum - 6 * nw[s]); /* mg_3d.h:819-821 */
-                        diffs[0] = diff;
-                        /* adding +0 leaves a sum of squares unchanged: a select, not a branch */
-                        if constexpr (RES == 1)
-                            if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
-                                acc += own_upd[X] ? diff * diff : 0.;
-                    }
-                } else {
-                    const double diff = dd - a.invHsq * (sum - 6 * center); /* mg_3d.h:819-821 */
-                    nw[s] = center;
-                    diffs[S > 0 ? 1 : s - 1] = diff;
-                    if constexpr (RES == 1)
-                        if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
-                            acc += own_upd[X] ? diff * diff : 0.;
-                }
-            }
-            /* ---- stores: v' of plane i-S, r of plane i-S-2 (pairs complete at this step) */
-            if constexpr (S > 0) {
-                if (MG3D_AND(v_ok, row_own[rr])) { /* wave-uniform */
-                    const double other = last[rr][S - 1][X ^ 1]; /* finished one step ago */
-                    double2 o;
-                    o.x = X ? other : nw[S];
-                    o.y = X ? nw[S] : other;
-                    if (pair_own)
-                        st_stream(voutb + lane_off(row_off[rr]), o);
-                }
-            }
-            if constexpr (RES == 2 || (RES == 1 && RST)) { /* RST = false: the norm only, r is not assembled */
-                /* column X: the residual-only stage now; column X^1: the previous step's diff */
-                double2 o;
-                const double kept = RPARK ? rkpark[w * RJ + rr][lane] : rkeep[rr];
-                o.x = X ? kept : diffs[1];
-                o.y = X ? diffs[1] : kept;
-                if constexpr (RES == 2) { /* read by the NEXT step's restriction */
                     if constexpr (RPARK)
-                        rpark[w * RJ + rr][lane] = o;
+                        rkpark[w * RJ + rr][lane] = diffsG[g][0];
                     else
-                        rlag[rr] = o;
-                    if (rr == (CO == 0 ? RJ - 1 : 0))
-                        rex[par][w][lane] = o;
+                        rkeep[rr] = diffsG[g][0];
                 }
-                if (RES == 1 && MG3D_AND(MG3D_AND(r_ok, row_own[rr]), row_upd[rr])) { /* wave-uniform */
-                    double MG3D_GLOBAL *dst = reinterpret_cast<double MG3D_GLOBAL *>(routb + lane_off(row_off[rr]));
-                    if (own_both) {
-                        v2d x;
-                        x.x = o.x;
-                        x.y = o.y;
-                        *reinterpret_cast<v2d MG3D_GLOBAL *>(dst) = x;
-                    }
-                    if (k_edge_tile) { /* boundary entries of r are never written (mg_3d.h:824-825) */
-                        if (own_only0)
-                            dst[0] = o.x;
-                        if (own_only1)
-                            dst[1] = o.y;
-                    }
-                }
-                if constexpr (RPARK)
-                    rkpark[w * RJ + rr][lane] = diffs[0];
-                else
-                    rkeep[rr] = diffs[0];
+                /* ---- commit this row's new outputs */
+                in_prev[rr][0] = cur_v[rr].x;
+                in_prev[rr][1] = cur_v[rr].y;
+    #pragma unroll
+                for (int s = 0; s < ST; s++)
+                    last[rr][s][X] = nwG[g][s];
+
             }
-            /* ---- commit this row's new outputs */
-            in_prev[rr][0] = cur_v[rr].x;
-            in_prev[rr][1] = cur_v[rr].y;
-#pragma unroll
-            for (int s = 0; s < ST; s++)
-                last[rr][s][X] = nw[s];
         }
         /* age the d window (slots 0 .. ST-1 = planes i-1 .. i-ST) */
         if constexpr (DP > 0) {

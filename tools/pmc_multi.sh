@@ -5,6 +5,8 @@
 # At most FOUR counters of the TCP and of the TA block per pass: seven in one pass is more than the block can collect
 # (rocprofiler_create_counter_config: error 38, "Request exceeds the capabilities of the hardware to collect" -> rocprofv3
 # aborts with signal 6; round 3 misread that as a limitation of the pool).  A pass that fails stops the script.
+# Round 4: with four per pass the TCP_* groups collect (profiles/r04_legs_pmc_multi.txt); the TA_* group still aborts rocprofv3
+# (signal 6 in the counter set-up, then a hung tool: gpurun_out/r4legs/p7.err) even at four counters -- left out.
 tag=${1:-pmc}; shift
 prog=("$@"); [ ${#prog[@]} -eq 0 ] && prog=(python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline)
 out=gpurun_out/$tag
@@ -25,8 +27,6 @@ SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MI
 SQ_WAVES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INST_CYCLES_VMEM_RD
 TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum
 TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
-TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum
-TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_TAG_STALL_sum TCC_BUSY_avr
 TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_LEVEL_sum TCC_CYCLE_sum TCC_EA0_RDREQ_32B_sum
 GROUPS
