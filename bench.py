@@ -456,7 +456,7 @@ def main():
                 "rccl_ranks": rccl_ranks, "halo_overlap": overlap,
                 "ranks": [{"rank": r, "device": d, "name": n} for r, d, n in placement],
                 # where each rank's cycle went (ms per cycle, event pairs inside the timed region): kernels on its slabs,
-                # exchanges on the compute stream, exchanges overlapped on the communication stream, coarse levels
+                # exchanges the compute stream waits for at once, exchanges overlapped (u halos), coarse levels
                 "per_rank_ms": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in pr.items()} for pr in per_rank],
                 "coarse_policy": "rank 0 only (MG3D_COARSE_GATHER=1)" if os.environ.get("MG3D_COARSE_GATHER") == "1"
                 else "replicated on every rank",

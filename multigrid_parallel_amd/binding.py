@@ -496,9 +496,9 @@ class DistSolver:
         check(self.L.mg3d_dist_timing_enable(self._h, int(on)))
 
     def timing(self):
-        """per-cycle means since timing_enable(True): whole cycle, exchanges on the compute stream, exchanges on the
-        communication stream (overlapped), the replicated / rank-0 coarse levels; kernels on the distributed levels are
-        what is left of the cycle"""
+        """per-cycle means since timing_enable(True): whole cycle, exchanges the compute stream waits for at once
+        (critical path), exchanges that run overlapped (the u halos, underneath the launches in between), the
+        replicated / rank-0 coarse levels; kernels on the distributed levels are what is left of the cycle"""
         ms = (C.c_double * 4)()
         n = C.c_int(0)
         check(self.L.mg3d_dist_timing_get(self._h, ms, C.byref(n)))
