@@ -326,7 +326,7 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print the per-level stage table to stderr")
     ap.add_argument("--timing-mode", type=int, default=6, help=argparse.SUPPRESS)  # A/B of the timer cost (0 = none)
     ap.add_argument("--no-alt-schedules", action="store_true",
-                    help="skip the two extra timed regions (option carry = 0, option legs = 1) reported beside `value`")
+                    help="skip the extra timed regions (the other two schedules) reported beside `value`")
     ap.add_argument("--f32", action="store_true",
                     help="BASELINE configs[4] on one GPU instead of the headline: fp32, damped Jacobi, F-cycle start "
                          "(parity unpinned); default size 9 8 2 = 1025^3")
@@ -501,11 +501,12 @@ def main():
     kt = solver.kernel_times()
     # the same K cycles with every cycle run on its own (MG3D_NO_CARRY=1: no launch shared between consecutive cycles,
     # csrc/mg3d_ctx.hip "carried cycles"), no timers: reported beside `value`; both schedules give the same bits
-    plain = legs = None
+    plain = legs = carried = None
     if world == 1 and not args.no_alt_schedules:
-        def timed_with(key, value, what):
-            old = solver.get_option(key)
-            solver.set_option(key, value)  # the options API (mg3d_ctx_set_option): no environment on any launch path
+        def timed_with(opts, what):
+            old = {k: solver.get_option(k) for k in opts}
+            for k, v in opts.items():
+                solver.set_option(k, v)  # the options API (mg3d_ctx_set_option): no environment on any launch path
             try:
                 solver.vcycles(3)
                 barrier(solver)
@@ -515,13 +516,24 @@ def main():
                 el1 = time.perf_counter() - t1
                 return {"value": args.steps / el1, "ms_per_step": el1 / args.steps * 1e3, "what": what}
             finally:
-                solver.set_option(key, old)
-        if solver.get_option("carry") and not solver.get_option("legs"):
-            plain = timed_with("carry", 0, "option carry = 0: four launches per cycle on the finest level, none shared between cycles")
-        if not solver.get_option("legs"):
-            legs = timed_with("legs", 1, "option legs = 1 (opt-in, round 4): ONE launch per leg on the finest level -- prolongation + "
-                                         "four passes, three passes + residual + restriction, the norm's halves taken from either "
-                                         "side; 6.75 GB compulsory per cycle instead of 10.0, at one wave per SIMD (issue-bound)")
+                for k, v in old.items():
+                    solver.set_option(k, v)
+        N_min_legs, N_min_carry = solver.get_option("legs_min"), solver.get_option("carry_min")
+        is_legs = bool(solver.get_option("legs")) and N >= N_min_legs and nu == 2
+        is_carried = not is_legs and bool(solver.get_option("carry")) and N >= N_min_carry and nu == 2
+        # the other schedules beside the configured one (same bits, see tests/test_gpu_parity.py, tests/test_gpu_legs.py)
+        if is_legs or is_carried:
+            plain = timed_with({"legs": 0, "carry": 0}, "options legs = 0, carry = 0: four launches per cycle on the finest level, none "
+                                                        "shared between cycles")
+        if not is_carried:
+            carried = timed_with({"legs": 0, "carry": 1, "carry_min": min(N_min_carry, N)},
+                                 "options legs = 0, carry = 1: consecutive cycles share a launch (three memory-bound launches per "
+                                 "cycle on the finest level, 10.0 GB compulsory; the default below 450 points per side)")
+        if not is_legs:
+            legs = timed_with({"legs": 1, "legs_min": min(N_min_legs, N)},
+                              "option legs = 1: ONE launch per leg on the finest level -- prolongation + four passes, three passes + "
+                              "residual + restriction, the norm's halves taken from either side; 6.75 GB compulsory per cycle "
+                              "instead of 10.0, at one wave per SIMD (issue-bound; the default from 450 points per side)")
     fin = L - 1
     n_f = N ** 3
 
@@ -665,6 +677,7 @@ def main():
             "schedule": "one launch per leg" if any(r["kernel"] == "leg_up" for r in launches_tab) else
                         "carried cycles" if any(r["kernel"] == "sweep4+norm" for r in launches_tab) else "plain",
             "plain_schedule": plain,
+            "carried_schedule": carried,
             "legs_schedule": legs,
             "roofline": roof,
         }

@@ -112,10 +112,10 @@ int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm);
  * (every grid value -- u, d, r of every level -- is that of separate cycles, bit for bit; the returned norm sums the same
  * squares in another grouping of per-block partial sums and agrees to the summation tolerance, <= 1e-13 relative against
  * the exactly rounded sum: tests/test_gpu_parity.py; MG3D_NO_CARRY=1 switches it off).
- * MG3D_LEGS=1 (opt-in, round 4): one launch per leg on the finest level instead -- prolongation + four passes, three
- * passes + residual + restriction -- with the norm's two halves taken from the launches on either side of it; behind a
- * single mg3d_vcycle the next cycle's down-leg runs ahead into spare buffers and is swapped back when anything else is
- * asked (csrc/mg3d_ctx.hip, mg3d_can_legs).  Same bits. */
+ * From 450 points per side (options legs, legs_min; round 4) the finest level runs ONE launch per leg instead --
+ * prolongation + four passes, three passes + residual + restriction -- with the norm's two halves taken from the launches
+ * on either side of it; behind a single mg3d_vcycle the next cycle's down-leg runs ahead into spare buffers and is swapped
+ * back when anything else is asked (csrc/mg3d_ctx.hip, mg3d_can_legs).  Same bits; option legs = 0 keeps the carried cycles. */
 int mg3d_vcycle(mg3d_ctx *ctx, int level, double *norm);
 int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms);
 
@@ -132,8 +132,8 @@ int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level);
  *   key             default  environment at creation   meaning
  *   carry           1        MG3D_NO_CARRY=1 -> 0      consecutive V(2,2) cycles share a launch on the finest level
  *   carry_min       130      MG3D_CARRY_MIN            ... from this many points per side
- *   legs            0        MG3D_LEGS                 one launch per leg on the finest level instead (see above)
- *   legs_min        130      MG3D_LEGS_MIN             ... from this many points per side
+ *   legs            1        MG3D_LEGS                 one launch per leg on the finest level instead (see above)
+ *   legs_min        450      MG3D_LEGS_MIN             ... from this many points per side (below: the carried cycles)
  *   tiny            1        MG3D_NO_TINY=1 -> 0       the level above the coarsest one in one workgroup
  *   tiny_cycle      1        MG3D_NO_TINY_CYCLE=1 -> 0 ... together with the direct solve in one launch
  *   lu_reduced      1        MG3D_LU_REDUCED           install the factor without its identity rows (read per factor)

@@ -197,8 +197,8 @@ struct OptionRow {
 static const OptionRow kOptionTable[MG3D_OPT_COUNT] = {
     {"carry", "MG3D_NO_CARRY", 1, 1},
     {"carry_min", "MG3D_CARRY_MIN", 0, 130},
-    {"legs", "MG3D_LEGS", 0, 0},
-    {"legs_min", "MG3D_LEGS_MIN", 0, 130},
+    {"legs", "MG3D_LEGS", 0, 1},
+    {"legs_min", "MG3D_LEGS_MIN", 0, 450},
     {"tiny", "MG3D_NO_TINY", 1, 1},
     {"tiny_cycle", "MG3D_NO_TINY_CYCLE", 1, 1},
     {"lu_reduced", "MG3D_LU_REDUCED", 0, 1},
@@ -943,7 +943,9 @@ extern "C" int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm)
  * cycle's own u is the up-leg's output: nothing is speculative inside mg3d_vcycles.  Behind a single mg3d_vcycle call
  * the next cycle's down-leg runs at once, into the alt buffers (u of the top level, d of the level below), so that the
  * norm is complete when the call returns; whatever the caller does instead of another cycle swaps back
- * (mg3d_drop_carry: no launch).  Same conditions as the carried cycles; MG3D_LEGS=0 / 1 switches it off / on. */
+ * (mg3d_drop_carry: no launch).  Same conditions as the carried cycles.  Default from 450 points per side (option
+ * legs_min): same-box A/B by size, round 4 (ms per cycle, carried / legs): 385^3 1.23 / 1.30, 513^3 2.53 / 2.45, 641^3 4.99 / 4.80,
+ * 769^3 11.31 / 10.76, 1025^3 20.65 / 16.79 (profiles/r04_legs_by_size.txt); option legs = 0 keeps the carried cycles. */
 bool mg3d_can_legs(const mg3d_ctx *ctx, int q)
 {
     if (!ctx->opt.v[MG3D_OPT_LEGS])

@@ -242,15 +242,18 @@ def test_reference_test_mg_3d_fmg_start(tmp_path, c, L, nu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("carry_min", [None, "66"])
-def test_reference_test_mg_3d_129_cubed(tmp_path, monkeypatch, carry_min):
-    """BASELINE configs[1]: `9 5 2` = 129^3, V(2,2), through the unchanged reference driver.  carry_min = 66: the solve
-    loop's cycles run ahead into each other (carried cycles, default from 257^3 up) -- same history, same error norm: the
-    final SolverGetDetails / error check sees the finished cycle's own u."""
+@pytest.mark.parametrize("schedule", ["default", "carried", "legs"])
+def test_reference_test_mg_3d_129_cubed(tmp_path, monkeypatch, schedule):
+    """BASELINE configs[1]: `9 5 2` = 129^3, V(2,2), through the unchanged reference driver.  "carried": the solve
+    loop's cycles run ahead into each other (carried cycles, the default from 130 to 449 points per side); "legs": one
+    launch per leg with the next cycle's down-leg run ahead behind every SolverLinSolve (the default from 450 points per
+    side) -- same history, same error norm: the final SolverGetDetails / error check sees the finished cycle's own u."""
     if not os.path.exists(BIN1):
         pytest.skip("oracle/_ref/dropin_test_mg_3d was not built")
-    if carry_min:
-        monkeypatch.setenv("MG3D_CARRY_MIN", carry_min)
+    if schedule == "carried":
+        monkeypatch.setenv("MG3D_CARRY_MIN", "66")
+    if schedule == "legs":
+        monkeypatch.setenv("MG3D_LEGS_MIN", "66")
     known = [600893, 73400.9, 9566.66, 1305, 183.942, 26.5851, 3.92421, 0.590481, 0.0904885, 0.014113, 0.00223841,
              0.000360659, 5.89564e-05, 9.7633e-06, 1.63505e-06]
     r = run([BIN1, "9", "5", "2"], tmp_path, 2)

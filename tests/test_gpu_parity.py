@@ -596,25 +596,37 @@ def test_host_vcycle_started_below_the_finest_level():
 
 
 def test_full_size_513_bit_exact_against_oracle(monkeypatch):
-    """BASELINE's headline size, three V(2,2) cycles (carried cycles, the default at this size: the second cycle both
-    continues the first and runs ahead into the third): the whole 513^3 solution vector (1.08 GB) is bit-identical to the
-    oracle's (OpenMP over the host cores; the oracle's grid values do not depend on the thread count) -- and to the
-    plain schedule's."""
+    """BASELINE's headline size, three V(2,2) cycles in each of the three schedules -- one launch per leg (the default at
+    this size since round 4), carried cycles (option legs = 0: the second cycle both continues the first and runs ahead
+    into the third), plain (carry = 0 too): the whole 513^3 solution vector (1.08 GB) is bit-identical to the oracle's
+    (OpenMP over the host cores; the oracle's grid values do not depend on the thread count) every time."""
     O.lib().orc_set_threads(min(16, os.cpu_count() or 1))
     want_norms, want_u, _, _ = O.run_problem(9, 7, 2, 3)
     with M.Solver(9, 7, 2) as s:
         s.setup_test_problem()
         s.timing_enable(3)
         got = s.vcycles(3)
-        assert {kn: n for (lvl, kn), (n, _) in s.kernel_times().items() if lvl == 6}.get("sweep4+norm") == 2
+        kt = {kn: n for (lvl, kn), (n, _) in s.kernel_times().items() if lvl == 6}
+        assert kt.get("leg_up") == 3 and kt.get("leg_down") == 2 and "sweep4+norm" not in kt, kt
         s.timing_enable(0)
         u = s.download(MG3D_U, 6)
         assert_norm_exact(s, 6, got[-1])  # 133 M squares: the GPU's tree sum against the exactly rounded one, 1e-13
     assert np.array_equal(u, want_u)
     np.testing.assert_allclose(got, want_norms, rtol=norm_rtol(513))
     O.lib().orc_set_threads(1)
-    monkeypatch.setenv("MG3D_NO_CARRY", "1")
     with M.Solver(9, 7, 2) as s:
+        s.set_option("legs", 0)
+        s.setup_test_problem()
+        s.timing_enable(3)
+        carried = s.vcycles(3)
+        assert {kn: n for (lvl, kn), (n, _) in s.kernel_times().items() if lvl == 6}.get("sweep4+norm") == 2
+        s.timing_enable(0)
+        assert np.array_equal(s.download(MG3D_U, 6), want_u)
+        assert_norm_exact(s, 6, carried[-1])
+    np.testing.assert_allclose(carried, want_norms, rtol=norm_rtol(513))
+    with M.Solver(9, 7, 2) as s:
+        s.set_option("legs", 0)
+        s.set_option("carry", 0)
         s.setup_test_problem()
         plain = s.vcycles(3)
         assert np.array_equal(s.download(MG3D_U, 6), want_u)
@@ -909,7 +921,8 @@ def test_options_are_per_context_and_set_through_the_api(monkeypatch):
     monkeypatch.delenv("MG3D_NO_CARRY", raising=False)
     monkeypatch.setenv("MG3D_CARRY_MIN", "66")
     with M.Solver(9, 5, 2) as a, M.Solver(9, 5, 2) as b:
-        assert a.get_option("carry") == 1 and a.get_option("carry_min") == 66 and a.get_option("legs") == 0
+        assert a.get_option("carry") == 1 and a.get_option("carry_min") == 66
+        assert a.get_option("legs") == 1 and a.get_option("legs_min") == 450  # (129^3 < 450: the carried cycles run here)
         assert set(a.options()) >= {"carry", "carry_min", "legs", "legs_min", "tiny", "tiny_cycle", "lu_reduced", "fuse_rst2",
                                     "small_max", "fuse_leg_max", "fuse_up_max", "sweep_tune", "sweep_ci"}
         monkeypatch.setenv("MG3D_NO_CARRY", "1")  # after creation: nobody reads it any more

@@ -5,7 +5,7 @@ import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['r
 run default
 # (round 4: the switches whose A/B round 3 settled -- tightest k-tiles, the XCD groupings, 4 + 0 up-leg, r-assembling norm launch --
 # are gone from the library; what is left are the options of include/mg3d.h, here through their environment overrides, plus MG3D_LEGS)
-for kv in MG3D_NO_CARRY=1 MG3D_LEGS=1 MG3D_NO_TINY=1 MG3D_NO_TINY_CYCLE=1 MG3D_LU_REDUCED=0 MG3D_SWEEP_TUNE=0 MG3D_SMALL_MAX=0 MG3D_SMALL_MAX=65 MG3D_FUSE_LEG_MAX=65 MG3D_FUSE_UP_MAX=65 MG3D_FUSE_RST2=0; do
+for kv in MG3D_LEGS=0 "MG3D_LEGS=0 MG3D_NO_CARRY=1" MG3D_NO_TINY=1 MG3D_NO_TINY_CYCLE=1 MG3D_LU_REDUCED=0 MG3D_SWEEP_TUNE=0 MG3D_SMALL_MAX=0 MG3D_SMALL_MAX=65 MG3D_FUSE_LEG_MAX=65 MG3D_FUSE_UP_MAX=65 MG3D_FUSE_RST2=0; do
   ( export $kv; run $kv )
 done
 run default
