@@ -1,4 +1,5 @@
-"""scratch probe (round 4): finest-level launch times of the one-launch-per-leg schedule at 513^3."""
+"""Finest-level launch times of a schedule at 513^3 (LEVELS=n for another size): MG3D_LEGS=1 (default) one launch per leg,
+MG3D_LEGS=0 the carried cycles; with MG3D_LIB_PATH an A/B against another build of the library (tools/build_variant.sh)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

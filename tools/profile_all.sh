@@ -1,3 +1,5 @@
+#!/bin/bash
+# usage (on the GPU box): tools/profile_all.sh  -- everything profiles/ holds for round 4 in one go (copy the r04_* files from gpurun_out/)
 tools/profile_round.sh r04 > gpurun_out/prof_r04.log 2>&1; tail -3 gpurun_out/prof_r04.log
 tools/profile_legs.sh r04 > gpurun_out/prof_r04_legs.log 2>&1; tail -3 gpurun_out/prof_r04_legs.log
 tools/profile_f32.sh r04 > gpurun_out/prof_r04_f32.log 2>&1; tail -3 gpurun_out/prof_r04_f32.log
