@@ -185,3 +185,40 @@ def test_bench_self_launch_explains_missing_gpus():
     assert r.returncode == 2
     assert "needs 64 visible GPUs" in r.stderr and "one rank per GPU" in r.stderr
     assert r.stdout.strip() == ""
+
+
+def test_option_keys_match_the_documented_tables():
+    """mg3d_option_name enumerates the launch / schedule options (no GPU needed); the table in include/mg3d.h and the one in
+    INTEGRATION.md name exactly these keys, and no product source reads the environment outside context creation."""
+    L = M.lib()
+    keys, i = [], 0
+    while L.mg3d_option_name(i):
+        keys.append(L.mg3d_option_name(i).decode())
+        i += 1
+    assert len(keys) == len(set(keys)) >= 15 and "carry" in keys and "legs" in keys
+    hdr = open(os.path.join(ROOT, "include", "mg3d.h")).read()
+    block = hdr[hdr.index(" *   key             default"):hdr.index("int mg3d_ctx_set_option")]
+    doc = re.findall(r"^ \*   ([a-z_0-9/]+)\s+-?\d", block, flags=re.M)
+    expand = lambda names: sorted(k for n in names for k in (["sweep_rj", "sweep_nw", "sweep_pf"] if n == "sweep_rj/nw/pf" else [n]))
+    assert expand(doc) == sorted(keys), (expand(doc), sorted(keys))
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = integ[integ.index("| key (`mg3d_ctx_set_option`)"):integ.index("Read at creation only, no key")]
+    tkeys = []
+    for row in table.splitlines()[2:]:
+        cell = row.split("|")[1] if row.count("|") > 3 else ""
+        if "fp32" in cell:
+            continue
+        tkeys += re.findall(r"`([a-z_0-9]+)`", cell)
+    assert sorted(tkeys) == sorted(keys), (sorted(tkeys), sorted(keys))
+    # getenv only where a context / handle is created (or in host-side planning that has no handle)
+    allowed = {"mg3d_ctx.hip": {"mg3d_options_init", "ctx_new"}, "mg3d_dist.hip": {"mg3d_dist_create", "mg3d_slab_first_level"},
+               "mg3d_f32.hip": {"mg3d32_create_slabs"}}
+    csrc = os.path.join(ROOT, "multigrid_parallel_amd", "csrc")
+    for f in os.listdir(csrc):
+        if not f.endswith((".hip", ".h", ".c")):
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        for m in re.finditer(r"getenv\(", src):
+            head = src[:m.start()]
+            fn = re.findall(r"^(?:extern \"C\" |static )?[a-zA-Z_][\w \*]*?\b(\w+)\([^;{]*\)\s*\n?\{", head, flags=re.M)
+            assert f in allowed and fn and fn[-1] in allowed[f], f"getenv in {f} inside {fn[-1] if fn else '?'}"
