@@ -612,6 +612,13 @@ def main():
             "finest_level_launches": launches_tab}
     if pmc_note:
         roof["traffic_note"] = pmc_note
+    if any(r["kernel"] == "leg_up" for r in launches_tab):
+        roof["schedule_note"] = ("one launch per leg (default from 450 points per side): the finest level streams through the chip twice "
+                                 "per cycle instead of three times (6.75 instead of 10.0 GB compulsory, 7.8 instead of 11.4 GB HBM-side); "
+                                 "its two launches hold six-plane windows, which only fit at one wave per SIMD, where a step is bound "
+                                 "by instruction issue, not by bytes -- hence a LOWER per-launch fraction of the HBM roofline than the "
+                                 "carried schedule's memory-bound launches (0.60-0.65, see carried_schedule: same bits, a 3-5 % slower "
+                                 "cycle) for a FASTER cycle; vcycle_frac_of_hbm_peak is the figure that improves")
     # cycles of the timed region that carried the markers: all of them (--breakdown, mode 3) or every (mode - 2)-th
     tmode = 1 if args.breakdown else args.timing_mode
     sampled = args.steps if tmode < 4 else len(range(0, args.steps, tmode - 2))
