@@ -469,8 +469,14 @@ static int sweep_impl(const mg3d_options &o, const Geom &g, const double *vin, c
  *   up:   prolongation (:1331) folded into the loads, four post-smoothing passes black, red, black, red (:1341).
  *         partials != NULL: the sum of diff^2 of the RESULT over the colour the last pass has updated (red) -- the first
  *         half of the cycle's residual norm; the other half is formed by the next down-leg (or by a norm-only launch). */
+/* the up-leg's shape: four rows a thread, eight waves (two waves per SIMD, two slots of the d window parked in LDS: 249 VGPRs,
+ * no scratch since the prolongation is applied at the end of the previous step, MG3D_PRO_LATE) or eight rows, four waves (one
+ * wave per SIMD, three slots parked: the shape of round 4's first version, bound by instruction issue) */
+#ifndef MG3D_LEG_UP_RJ
+#define MG3D_LEG_UP_RJ 4
+#endif
 #ifndef MG3D_LEG_DP_UP
-#define MG3D_LEG_DP_UP 3
+#define MG3D_LEG_DP_UP (MG3D_LEG_UP_RJ == 4 ? 2 : 3)
 #endif
 #ifndef MG3D_LEG_DP_DOWN3
 #define MG3D_LEG_DP_DOWN3 2
@@ -531,9 +537,15 @@ int k_sweep_leg_up(const mg3d_options &o, const Geom &g, const double *vin, cons
         return 0;
     a.ec = ec;
     a.gce = gce;
+#if MG3D_LEG_UP_RJ == 4
+    if (partials)
+        return launch_sweep<4, 0, 4, 8, 1, true, true, MG3D_LEG_DP_UP, 4>(o, a, max_partials, s);
+    return launch_sweep<4, 0, 4, 8, 1, true, true, MG3D_LEG_DP_UP, -1>(o, a, max_partials, s);
+#else
     if (partials)
         return launch_sweep<4, 0, 8, 4, 1, true, true, MG3D_LEG_DP_UP, 4>(o, a, max_partials, s);
     return launch_sweep<4, 0, 8, 4, 1, true, true, MG3D_LEG_DP_UP, -1>(o, a, max_partials, s);
+#endif
 }
 
 int k_sweep(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, double *r, double *partials,

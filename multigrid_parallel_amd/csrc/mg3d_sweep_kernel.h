@@ -457,15 +457,64 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
         }
     };
     int have_hi = 0; /* highest coarse plane staged so far */
+    /* v_in = u + P(ec) of fine local plane ip (global parity OI), added into the plane's registers: parents summed in the
+     * reference's order per parity class (see prolong_kernel) */
+    auto prolong_into = [&](double2(&vv)[RJ], int ip, auto oi_c) {
+        constexpr int oi = decltype(oi_c)::value;
+        const int s0 = slot_of(coarse_of(ip)), s1 = slot_of(coarse_of(ip) + 1);
+#pragma unroll
+        for (int rr = 0; rr < RJ; rr++) {
+            const int oj = rr & 1; /* jrow0 is even */
+            const int lr = (w * RJ + rr) >> 1;
+            const double e000 = cpl[s0][lr][lane], e001 = cpl[s0][lr][lane + 1];
+            double t0, t1;
+            if (!oi && !oj) {
+                t0 = e000;
+                t1 = (e000 + e001) * 0.5;
+            } else if (!oi) {
+                const double e010 = cpl[s0][lr + 1][lane], e011 = cpl[s0][lr + 1][lane + 1];
+                t0 = (e000 + e010) * 0.5;
+                t1 = (((e000 + e010) + e001) + e011) * 0.25;
+            } else if (!oj) {
+                const double e100 = cpl[s1][lr][lane], e101 = cpl[s1][lr][lane + 1];
+                t0 = (e000 + e100) * 0.5;
+                t1 = (((e000 + e100) + e001) + e101) * 0.25;
+            } else {
+                const double e010 = cpl[s0][lr + 1][lane], e011 = cpl[s0][lr + 1][lane + 1];
+                const double e100 = cpl[s1][lr][lane], e101 = cpl[s1][lr][lane + 1];
+                const double e110 = cpl[s1][lr + 1][lane], e111 = cpl[s1][lr + 1][lane + 1];
+                t0 = (((e000 + e010) + e100) + e110) * 0.25;
+                double t = e000 + e001;
+                t = t + e010;
+                t = t + e011;
+                t = t + e100;
+                t = t + e101;
+                t = t + e110;
+                t = t + e111;
+                t1 = t * 0.125;
+            }
+            vv[rr].x += t0;
+            vv[rr].y += t1;
+        }
+    };
+    /* MG3D_PRO_LATE: a plane receives its prolongation at the END of the step before the one that consumes it (behind the
+     * step's stores, in the registers the load has landed in), not at the top of its own step -- where the plane in use,
+     * the plane in flight, the whole window and the parents of a row are all live at once: that peak is what kept the
+     * prolonging four-pass shape from two waves per SIMD (256 VGPRs + 68 bytes of scratch).  The coarse planes are staged
+     * one step earlier for it (three primed instead of two). */
+#ifndef MG3D_PRO_LATE
+#define MG3D_PRO_LATE 1
+#endif
+    static_assert(!PRO || PF <= 2, "PRO: one or two planes in flight");
     if constexpr (PRO) {
         double buf[CPT];
         const int c0 = coarse_of(i_s);
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
+        for (int c = 0; c < (MG3D_PRO_LATE ? 3 : 2); c++) {
             coarse_fetch(c0 + c, buf);
             coarse_put(c0 + c, buf);
         }
-        have_hi = c0 + 1;
+        have_hi = c0 + (MG3D_PRO_LATE ? 2 : 1);
         __syncthreads();
     }
 
@@ -473,6 +522,8 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
 #pragma unroll
     for (int f = 0; f < PF; f++)
         load_plane(i_s + f, nxt_v[f], nxt_d[f]);
+    if constexpr (PRO && MG3D_PRO_LATE != 0)
+        prolong_into(nxt_v[0], i_s, std::integral_constant<int, 1>{}); /* plane i_s is odd in the step parity's sense (see the step) */
 
     int ring = 0; /* DP > 0: LDS ring slot this step's parked plane goes to (= step number mod DP) */
     auto step = [&](int pl, auto par_c) {
@@ -526,55 +577,22 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
         double cbuf[CPT];
         bool stage_new = false;
         if constexpr (PRO) {
-            /* the next step needs coarse planes up to coarse_of(i+1)+1: fetch one now, publish before the barrier */
-            stage_new = coarse_of(i + 1) + 1 > have_hi;
-            if (stage_new)
-                coarse_fetch(have_hi + 1, cbuf);
-            /* v_in = u + P(ec): parents summed in the reference's order per parity class (see prolong_kernel) */
-            /* parity of the plane's global index: the segment starts where (ig0 + i_s + jt0 + 1 + c1) is even, a PRO tile
+            /* parity of a plane's global index: the segment starts where (ig0 + i_s + jt0 + 1 + c1) is even, a PRO tile
              * starts on an even row and PRO launches are post-smoothers (c1 = 0, the launchers refuse anything else), so it
-             * is the step's parity -- known at compile time: the parent ladder below is straight-line code */
+             * is the step's parity -- known at compile time: the parent ladder is straight-line code */
             static_assert(!PRO || (HJ % 2 == 0 && VJ % 2 == 0), "PRO: tiles start on even rows");
-            constexpr int oi = (1 + PAR) & 1;
-            const int s0 = slot_of(coarse_of(i)), s1 = slot_of(coarse_of(i) + 1);
-#pragma unroll
-            for (int rr = 0; rr < RJ; rr++) {
-                const int oj = rr & 1; /* jrow0 is even */
-                const int lr = (w * RJ + rr) >> 1;
-                const double e000 = cpl[s0][lr][lane], e001 = cpl[s0][lr][lane + 1];
-                double t0, t1;
-                if (!oi && !oj) {
-                    t0 = e000;
-                    t1 = (e000 + e001) * 0.5;
-                } else if (!oi) {
-                    const double e010 = cpl[s0][lr + 1][lane], e011 = cpl[s0][lr + 1][lane + 1];
-                    t0 = (e000 + e010) * 0.5;
-                    t1 = (((e000 + e010) + e001) + e011) * 0.25;
-                } else if (!oj) {
-                    const double e100 = cpl[s1][lr][lane], e101 = cpl[s1][lr][lane + 1];
-                    t0 = (e000 + e100) * 0.5;
-                    t1 = (((e000 + e100) + e001) + e101) * 0.25;
-                } else {
-                    const double e010 = cpl[s0][lr + 1][lane], e011 = cpl[s0][lr + 1][lane + 1];
-                    const double e100 = cpl[s1][lr][lane], e101 = cpl[s1][lr][lane + 1];
-                    const double e110 = cpl[s1][lr + 1][lane], e111 = cpl[s1][lr + 1][lane + 1];
-                    t0 = (((e000 + e010) + e100) + e110) * 0.25;
-                    double t = e000 + e001;
-                    t = t + e010;
-                    t = t + e011;
-                    t = t + e100;
-                    t = t + e101;
-                    t = t + e110;
-                    t = t + e111;
-                    t1 = t * 0.125;
-                }
-                cur_v[rr].x += t0;
-                cur_v[rr].y += t1;
-#ifdef MG3D_PRO_SCHED_BARRIER
-                /* one row's parents at a time: left alone the scheduler hoists every row's LDS reads to the top of the step
-                 * (up to eight doubles a row), which is what pushes the shapes at the register limit into scratch */
-                __builtin_amdgcn_sched_barrier(0);
-#endif
+            if constexpr (MG3D_PRO_LATE != 0) {
+                /* the END of this step prolongs plane i + 1, the end of the next one plane i + 2: its parents (up to coarse
+                 * plane coarse_of(i + 2) + 1) are fetched now and published before this step's barrier */
+                stage_new = coarse_of(i + 2) + 1 > have_hi;
+                if (stage_new)
+                    coarse_fetch(have_hi + 1, cbuf);
+            } else {
+                /* the next step needs coarse planes up to coarse_of(i+1)+1: fetch one now, publish before the barrier */
+                stage_new = coarse_of(i + 1) + 1 > have_hi;
+                if (stage_new)
+                    coarse_fetch(have_hi + 1, cbuf);
+                prolong_into(cur_v, i, std::integral_constant<int, (1 + PAR) & 1>{});
             }
         }
 
@@ -893,6 +911,8 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
             ex[par][w][1][s][lane] = last[RJ - 1][s][(PAR + RJ - 1) & 1];
         }
         if constexpr (PRO) {
+            if constexpr (MG3D_PRO_LATE != 0)
+                prolong_into(nxt_v[PF == 2 ? (PAR ^ 1) : 0], i + 1, std::integral_constant<int, PAR & 1>{});
             if (stage_new) {
                 coarse_put(have_hi + 1, cbuf);
                 have_hi++;
