@@ -478,6 +478,11 @@ static int sweep_impl(const mg3d_options &o, const Geom &g, const double *vin, c
 #ifndef MG3D_LEG_DP_UP
 #define MG3D_LEG_DP_UP (MG3D_LEG_UP_RJ == 4 ? 2 : 3)
 #endif
+/* the down-leg's shape: four rows a thread, eight waves (two waves per SIMD: two slots of the d window parked in LDS, which the
+ * single copy of the wave-edge rows -- EXS in the kernel -- makes room for) or eight rows, four waves (one wave per SIMD) */
+#ifndef MG3D_LEG_DOWN_RJ
+#define MG3D_LEG_DOWN_RJ 4
+#endif
 #ifndef MG3D_LEG_DP_DOWN3
 #define MG3D_LEG_DP_DOWN3 2
 #endif
@@ -519,10 +524,17 @@ int k_sweep_leg_down(const mg3d_options &o, const Geom &g, const double *vin, co
     a.dc = dc;
     a.ic_lo = ic_lo >= 0 ? ic_lo : 0;
     a.ic_hi = ic_hi >= 0 ? ic_hi : gc.ni;
+#if MG3D_LEG_DOWN_RJ == 4
+    if (S == 3 && partials)
+        return launch_sweep<3, 2, 4, 8, 1, false, true, MG3D_LEG_DP_DOWN3, 0>(o, a, max_partials, s);
+    if (S == 3)
+        return launch_sweep<3, 2, 4, 8, 1, false, true, MG3D_LEG_DP_DOWN3, -1>(o, a, max_partials, s);
+#else
     if (S == 3 && partials)
         return launch_sweep<3, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN3, 0>(o, a, max_partials, s);
     if (S == 3)
         return launch_sweep<3, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN3, -1>(o, a, max_partials, s);
+#endif
     return -1;
 }
 

@@ -180,10 +180,19 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
     static_assert(VJ > 0 && ST >= 1, "tile too small");
     constexpr int STX = ST > 0 ? ST : 1;
 
-    /* edge rows exchanged between waves: [parity][wave][top/bottom][stage][lane] */
-    __shared__ double ex[2][NW][2][STX][WAVE];
+    /* edge rows exchanged between waves: [parity][wave][top/bottom][stage][lane].  Two copies, written at the end of a step
+     * and read at the top of the next, cost one barrier a step.  EXS: ONE copy and a second barrier behind the reads at the top
+     * of the step (every wave has just left the first one: what it waits for is the LDS latency of its own reads) -- at eight
+     * waves that frees 32 + 8 KB of LDS, what the restricting down-leg needs to park two slots of its d window and fit two
+     * waves per SIMD */
+#ifndef MG3D_EX_SINGLE
+#define MG3D_EX_SINGLE(S_, RES_, NW_, DP_) ((RES_) == 2 && (NW_) == 8 && (DP_) > 0)
+#endif
+    constexpr bool EXS = MG3D_EX_SINGLE(S, RES, NW, DP);
+    constexpr int EXB = EXS ? 1 : 2;
+    __shared__ double ex[EXB][NW][2][STX][WAVE];
     __shared__ double red[NW];
-    __shared__ double2 rex[RES == 2 ? 2 : 1][RES == 2 ? NW : 1][RES == 2 ? WAVE : 1]; /* r pair of a wave's last (CO = 0) / first (CO = 1) row */
+    __shared__ double2 rex[RES == 2 ? EXB : 1][RES == 2 ? NW : 1][RES == 2 ? WAVE : 1]; /* r pair of a wave's last (CO = 0) / first (CO = 1) row */
     /* RES == 2: the coarse rows a thread completes are centred on its rows 2c + CO -- the even rows of the LEVEL */
     constexpr int CO = RES == 2 ? (HJ & 1) : 0;
     /* PRO: three consecutive coarse planes of the tile's coarse footprint, [plane % 3][row][col] */
@@ -305,7 +314,10 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
     constexpr int DLAG = (MG3D_DLAG >> SHAPE_BIT) & 1;
     static_assert(DP == 0 || DLAG == 1, "the parked d window assumes d trails u by one plane");
     constexpr bool A32 = ((MG3D_ADDR32 >> SHAPE_BIT) & 1) != 0;
-    typename std::conditional<A32, unsigned, long long>::type row_off[RJ];
+    /* a row's offset = a wave-uniform part (row, scalar registers) + ONE per-lane part (column) for all rows: RJ - 1 VGPRs
+     * less than an offset per row */
+    unsigned row_base[RJ];
+    static_assert(A32, "32-bit offsets inside a plane");
 #pragma unroll
     for (int rr = 0; rr < RJ; rr++) {
         const int j = jrow0 + rr;
@@ -318,9 +330,11 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
          * they deliver there is never used -- a point of the level only reads neighbours inside the level, and the points
          * on its faces are passed through, not computed -- so clamping replaces a guard (two scalar ANDs, an EXEC save, a
          * branch and a restore per row and field: half of the step's scalar instructions) by nothing */
-        const int jc = j < 0 ? 0 : (j >= g.nj ? g.nj - 1 : j), kc = kA > g.pitch - 2 ? g.pitch - 2 : kA;
-        row_off[rr] = (decltype(row_off[0] + 0))(((long long)g.pitch * jc + kc) * (long long)sizeof(double));
+        const int jc = j < 0 ? 0 : (j >= g.nj ? g.nj - 1 : j), kc = 0;
+        (void)kc;
+        row_base[rr] = (unsigned)((long long)g.pitch * jc * (long long)sizeof(double));
     }
+    const unsigned col_off = (unsigned)((kA > g.pitch - 2 ? g.pitch - 2 : kA) * (int)sizeof(double));
     const bool col_in[2] = {kA >= 0 && kA < g.nk, kA + 1 >= 0 && kA + 1 < g.nk};
     const bool col_upd[2] = {kA >= 1 && kA <= g.nk - 2, kA + 1 >= 1 && kA + 1 <= g.nk - 2};
     const bool pair_own = kA >= own_klo && kA < own_khi && col_in[0];
@@ -333,15 +347,24 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
      * booleans the compiler emits -- the scalar registers it takes are spilled to VGPR lanes, v_readlane / v_writelane
      * 117 -> 327 per three steps, 4933 -> 5127 instructions: not kept) */
     const bool k_edge_tile = tk == 0 || tk == a.ntk - 1; /* only there a pair can have one updatable column */
+    /* the per-lane flags the plane loop tests, as bits of ONE register (a flag each costs a VGPR: with the scalar registers
+     * full the compiler keeps a lane's boolean as a 0 / 1 dword); taken through an opaque copy at the top of every step so
+     * that `flags & bit` is not hoisted out of the loop into one register per bit again */
+    enum { LM_UPD0 = 1, LM_UPD1 = 2, LM_OWN0 = 4, LM_OWN1 = 8, LM_PAIR = 16, LM_CCOL = 32, LM_BOTH = 64, LM_ONLY0 = 128, LM_ONLY1 = 256 };
+#define LM(bit) ((lm & (unsigned)(bit)) != 0u)
     /* RES == 2: the coarse points this thread completes -- rows centred on its even rows, its even column */
     bool crow_ok[RJ / 2];
-    long long dc_off[RJ / 2];
+    unsigned dc_row[RJ / 2]; /* wave-uniform: the coarse row's byte offset inside a coarse plane; the lane's part is its column */
+    const unsigned dc_col = (unsigned)((kA >> 1) * (int)sizeof(double));
     const bool ccol_ok = pair_own && (kA >> 1) >= 1 && (kA >> 1) <= a.gc.nk - 2;
+    const unsigned lmask = (col_upd[0] ? LM_UPD0 : 0) | (col_upd[1] ? LM_UPD1 : 0) | (own_upd[0] ? LM_OWN0 : 0) | (own_upd[1] ? LM_OWN1 : 0) |
+                           (pair_own ? LM_PAIR : 0) | (ccol_ok ? LM_CCOL : 0) | (own_both ? LM_BOTH : 0) | (own_only0 ? LM_ONLY0 : 0) |
+                           (own_only1 ? LM_ONLY1 : 0);
 #pragma unroll
     for (int c = 0; c < RJ / 2; c++) {
         const int jc = (jrow0 + 2 * c + CO) >> 1;
         crow_ok[c] = row_own[2 * c + CO] && jc >= 1 && jc <= a.gc.nj - 2;
-        dc_off[c] = (long long)a.gc.pitch * jc + (kA >> 1);
+        dc_row[c] = (unsigned)((long long)a.gc.pitch * (jc < 0 ? 0 : jc) * (long long)sizeof(double));
     }
 
     /* pipeline state (see header).  last[rr][s][c]: newest stage-s output of column c */
@@ -398,7 +421,7 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
         if (have_u) {
 #pragma unroll
             for (int rr = 0; rr < RJ; rr++) {
-                const gcbytes pu = ubase + lane_off(row_off[rr]);
+                const gcbytes pu = ubase + row_base[rr] + lane_off(col_off);
 #if (MG3D_NT & 8)
                 if (S == 0 && row_once[rr]) /* wave-uniform */
                     vv[rr] = ld_stream<8>(pu);
@@ -413,7 +436,7 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
         }
 #pragma unroll
         for (int rr = 0; rr < RJ; rr++) {
-            const gcbytes pd = dbase + lane_off(row_off[rr]);
+            const gcbytes pd = dbase + row_base[rr] + lane_off(col_off);
 #if (MG3D_NT & 8)
             if (S == 0 && row_once[rr])
                 dd[rr] = ld_stream<8>(pd);
@@ -530,6 +553,8 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
         constexpr int PAR = decltype(par_c)::value;
         const int i = i_s + pl; /* local plane just arrived */
         const int par = pl & 1;
+        unsigned lm = lmask;
+        asm volatile("" : "+v"(lm));
         /* current plane <- head of the prefetch queue, then request plane i+PF */
 #ifndef MG3D_PIN_LOADS
 #define MG3D_PIN_LOADS 0
@@ -634,13 +659,21 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
              * Not in the two shapes that sit at 256 VGPRs: there the eight unconditional reads at the top of the step
              * lengthen live ranges into scratch spills inside the plane loop (measured 0.68 -> 0.94 ms at 513^3). */
             if constexpr (MG3D_EDGE_UNCOND || (S < 4 && (RES != 2 || PF == 1))) {
-                e_top[s] = ex[par ^ 1][w > 0 ? w - 1 : 0][1][s][lane];
-                e_bot[s] = ex[par ^ 1][w < NW - 1 ? w + 1 : NW - 1][0][s][lane];
+                e_top[s] = ex[EXS ? 0 : par ^ 1][w > 0 ? w - 1 : 0][1][s][lane];
+                e_bot[s] = ex[EXS ? 0 : par ^ 1][w < NW - 1 ? w + 1 : NW - 1][0][s][lane];
             } else {
-                e_top[s] = (w > 0) ? ex[par ^ 1][w - 1][1][s][lane] : 0.;
-                e_bot[s] = (w < NW - 1) ? ex[par ^ 1][w + 1][0][s][lane] : 0.;
+                e_top[s] = (w > 0) ? ex[EXS ? 0 : par ^ 1][w - 1][1][s][lane] : 0.;
+                e_bot[s] = (w < NW - 1) ? ex[EXS ? 0 : par ^ 1][w + 1][0][s][lane] : 0.;
             }
         }
+        /* the one row of another wave a thread's restriction needs (RES == 2): CO = 0 the last row of the wave above (first
+         * coarse row), CO = 1 the first row of the wave below (last coarse row).  The outermost wave reads its own: a halo
+         * row's sum, never stored */
+        double2 nbr = make_double2(0., 0.);
+        if constexpr (RES == 2)
+            nbr = rex[EXS ? 0 : par ^ 1][CO == 0 ? (w > 0 ? w - 1 : 0) : (w < NW - 1 ? w + 1 : NW - 1)][lane];
+        if constexpr (EXS)
+            __syncthreads(); /* every wave holds its neighbours' rows: the single copy may be overwritten at the end of this step */
         /* store planes, bases in bytes */
         /* (planes outside the level: any product will do, the stores are guarded by v_ok / r_ok) */
         long long vbase = (long long)((unsigned long long)plane_bytes * (unsigned)(i - S)), rbase = (long long)((unsigned long long)plane_bytes * (unsigned)(i - ST));
@@ -677,9 +710,6 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
             /* (ig0 + i_s + jt0 + 1 + c1) is even, jt0 has the parity of HJ, the step's that of PAR */
             const bool odd = C1K >= 0 ? ((HJ + 1 + C1K + PAR + ST + 1) & 1) != 0 : (qg & 1) != 0;
             const double wi = odd ? 0.25 : 0.5;
-            /* the one row of another wave a thread needs: CO = 0 the last row of the wave above (first coarse row), CO = 1 the
-             * first row of the wave below (last coarse row).  The outermost wave reads its own: a halo row's sum, never stored */
-            const double2 nbr = rex[par ^ 1][CO == 0 ? (w > 0 ? w - 1 : 0) : (w < NW - 1 ? w + 1 : NW - 1)][lane];
 #pragma unroll
             for (int c = 0; c < RJ / 2; c++) {
                 double2 r0, r1, r2;
@@ -708,8 +738,11 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
                      * plane of the coarse level and one this launch is to write: one range of qq (rst_lo, rst_span) */
                     if (((unsigned)(qq - rst_lo) <= rst_span) & crow_ok[c]) { /* wave-uniform */
                         const int icl = ((qg - 1) >> 1) - a.gc.ig0;
-                        if (ccol_ok)
-                            a.dc[a.gc.plane * icl + dc_off[c]] = run;
+                        if (LM(LM_CCOL)) {
+                            const unsigned long long cb_ = reinterpret_cast<unsigned long long>(a.dc) +
+                                                           (unsigned long long)(a.gc.plane * icl) * sizeof(double) + dc_row[c];
+                            *reinterpret_cast<double MG3D_GLOBAL *>(reinterpret_cast<gbytes>(cb_) + lane_off(dc_col)) = run;
+                        }
                     }
                     double fresh = 0.;
 #pragma unroll
@@ -789,7 +822,7 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
         #else
                             const double val = a.sixth * (sum - a.hSq * dd); /* mg_3d.h:438-443 */
         #endif
-                            nwG[g][s] = (updu & col_upd[X]) ? val : center;
+                            nwG[g][s] = LM(updu ? (X ? LM_UPD1 : LM_UPD0) : 0) ? val : center;
                             if constexpr (HASTAP) {
                                 /* The tap: the residual norm of the state BETWEEN pass TAPQ and pass TAPQ + 1 without a stage of its
                                  * own.  The colour pass TAPQ has just updated: its residual uses that pass's neighbour sum (as
@@ -800,7 +833,7 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
                                 if (s == TAPQ || s == TAPQ + 1) {
                                     const double diff = dd - a.invHsq * (sum - 6 * (s == TAPQ ? nwG[g][s] : center));
                                     if ((updu & row_own[rr]) & acc_ok[s])
-                                        acc += own_upd[X] ? diff * diff : 0.;
+                                        acc += LM(X ? LM_OWN1 : LM_OWN0) ? diff * diff : 0.;
                                 }
                             }
                             if ((RES == 1 || RES == 2) && s == S) { /* residual of the point just updated: same six neighbours */
@@ -809,7 +842,7 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
                                 /* adding +0 leaves a sum of squares unchanged: a select, not a branch */
                                 if constexpr (RES == 1)
                                     if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
-                                        acc += own_upd[X] ? diff * diff : 0.;
+                                        acc += LM(X ? LM_OWN1 : LM_OWN0) ? diff * diff : 0.;
                             }
                         } else {
                             const double diff = dd - a.invHsq * (sum - 6 * center); /* mg_3d.h:819-821 */
@@ -817,7 +850,7 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
                             diffsG[g][S > 0 ? 1 : s - 1] = diff;
                             if constexpr (RES == 1)
                                 if (MG3D_AND(MG3D_AND(updu, row_own[rr]), acc_ok[s]))
-                                    acc += own_upd[X] ? diff * diff : 0.;
+                                    acc += LM(X ? LM_OWN1 : LM_OWN0) ? diff * diff : 0.;
                         }
 
                 }
@@ -833,8 +866,8 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
                         double2 o;
                         o.x = X ? other : nwG[g][S];
                         o.y = X ? nwG[g][S] : other;
-                        if (pair_own)
-                            st_stream(voutb + lane_off(row_off[rr]), o);
+                        if (LM(LM_PAIR))
+                            st_stream(voutb + row_base[rr] + lane_off(col_off), o);
                     }
                 }
                 if constexpr (RES == 2 || (RES == 1 && RST)) { /* RST = false: the norm only, r is not assembled */
@@ -849,20 +882,20 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
                         else
                             rlag[rr] = o;
                         if (rr == (CO == 0 ? RJ - 1 : 0))
-                            rex[par][w][lane] = o;
+                            rex[EXS ? 0 : par][w][lane] = o;
                     }
                     if (RES == 1 && MG3D_AND(MG3D_AND(r_ok, row_own[rr]), row_upd[rr])) { /* wave-uniform */
-                        double MG3D_GLOBAL *dst = reinterpret_cast<double MG3D_GLOBAL *>(routb + lane_off(row_off[rr]));
-                        if (own_both) {
+                        double MG3D_GLOBAL *dst = reinterpret_cast<double MG3D_GLOBAL *>(routb + row_base[rr] + lane_off(col_off));
+                        if (LM(LM_BOTH)) {
                             v2d x;
                             x.x = o.x;
                             x.y = o.y;
                             *reinterpret_cast<v2d MG3D_GLOBAL *>(dst) = x;
                         }
                         if (k_edge_tile) { /* boundary entries of r are never written (mg_3d.h:824-825) */
-                            if (own_only0)
+                            if (LM(LM_ONLY0))
                                 dst[0] = o.x;
-                            if (own_only1)
+                            if (LM(LM_ONLY1))
                                 dst[1] = o.y;
                         }
                     }
@@ -907,8 +940,8 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
         /* publish this wave's edge rows for the next step */
 #pragma unroll
         for (int s = 0; s < ST; s++) {
-            ex[par][w][0][s][lane] = last[0][s][(PAR + 0) & 1];
-            ex[par][w][1][s][lane] = last[RJ - 1][s][(PAR + RJ - 1) & 1];
+            ex[EXS ? 0 : par][w][0][s][lane] = last[0][s][(PAR + 0) & 1];
+            ex[EXS ? 0 : par][w][1][s][lane] = last[RJ - 1][s][(PAR + RJ - 1) & 1];
         }
         if constexpr (PRO) {
             if constexpr (MG3D_PRO_LATE != 0)
