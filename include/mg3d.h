@@ -112,7 +112,7 @@ int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm);
  * (every grid value -- u, d, r of every level -- is that of separate cycles, bit for bit; the returned norm sums the same
  * squares in another grouping of per-block partial sums and agrees to the summation tolerance, <= 1e-13 relative against
  * the exactly rounded sum: tests/test_gpu_parity.py; MG3D_NO_CARRY=1 switches it off).
- * From 450 points per side (options legs, legs_min; round 4) the finest level runs ONE launch per leg instead --
+ * From 160 points per side (options legs, legs_min; round 4) the finest level runs ONE launch per leg instead --
  * prolongation + four passes, three passes + residual + restriction -- with the norm's two halves taken from the launches
  * on either side of it; behind a single mg3d_vcycle the next cycle's down-leg runs ahead into spare buffers and is swapped
  * back when anything else is asked (csrc/mg3d_ctx.hip, mg3d_can_legs).  Same bits; option legs = 0 keeps the carried cycles. */
@@ -133,7 +133,7 @@ int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level);
  *   carry           1        MG3D_NO_CARRY=1 -> 0      consecutive V(2,2) cycles share a launch on the finest level
  *   carry_min       130      MG3D_CARRY_MIN            ... from this many points per side
  *   legs            1        MG3D_LEGS                 one launch per leg on the finest level instead (see above)
- *   legs_min        450      MG3D_LEGS_MIN             ... from this many points per side (below: the carried cycles)
+ *   legs_min        160      MG3D_LEGS_MIN             ... from this many points per side (below: the carried cycles)
  *   tiny            1        MG3D_NO_TINY=1 -> 0       the level above the coarsest one in one workgroup
  *   tiny_cycle      1        MG3D_NO_TINY_CYCLE=1 -> 0 ... together with the direct solve in one launch
  *   lu_reduced      1        MG3D_LU_REDUCED           install the factor without its identity rows (read per factor)
@@ -141,7 +141,8 @@ int mg3d_fill_boundary(mg3d_ctx *ctx, int field, int level);
  *                                                      per side, 0 never, 1 always
  *   small_max       129      MG3D_SMALL_MAX            largest level side that runs the two-rows-per-thread shapes
  *   fuse_leg_max    0        MG3D_FUSE_LEG_MAX         largest level side whose legs run as one (two-row) launch each
- *   fuse_up_max     0        MG3D_FUSE_UP_MAX          largest level side whose up-leg folds the prolongation into 4 passes
+ *   fuse_up_max     1048576  MG3D_FUSE_UP_MAX          largest level side whose up-leg folds the prolongation into 4 passes
+ *                                                      (default: every level; 0: the prolongation is its own launch below the top)
  *   sweep_tune      -1       MG3D_SWEEP_TUNE           first-use measurement of chunk lengths: -1 on unless the process
  *                                                      drives a multi-rank RCCL job, 0 off, 1 on
  *   sweep_tune_log  0        MG3D_SWEEP_TUNE_LOG       print the measured choices

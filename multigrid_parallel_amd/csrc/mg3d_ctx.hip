@@ -198,14 +198,14 @@ static const OptionRow kOptionTable[MG3D_OPT_COUNT] = {
     {"carry", "MG3D_NO_CARRY", 1, 1},
     {"carry_min", "MG3D_CARRY_MIN", 0, 130},
     {"legs", "MG3D_LEGS", 0, 1},
-    {"legs_min", "MG3D_LEGS_MIN", 0, 450},
+    {"legs_min", "MG3D_LEGS_MIN", 0, 160},
     {"tiny", "MG3D_NO_TINY", 1, 1},
     {"tiny_cycle", "MG3D_NO_TINY_CYCLE", 1, 1},
     {"lu_reduced", "MG3D_LU_REDUCED", 0, 1},
     {"fuse_rst2", "MG3D_FUSE_RST2", 0, -1},
     {"small_max", "MG3D_SMALL_MAX", 0, 129},
     {"fuse_leg_max", "MG3D_FUSE_LEG_MAX", 0, 0},
-    {"fuse_up_max", "MG3D_FUSE_UP_MAX", 0, 0},
+    {"fuse_up_max", "MG3D_FUSE_UP_MAX", 0, 1 << 20},
     {"sweep_tune", "MG3D_SWEEP_TUNE", 0, -1},
     {"sweep_tune_log", "MG3D_SWEEP_TUNE_LOG", 0, 0},
     {"sweep_ci", "MG3D_SWEEP_CI", 0, 0},
@@ -809,9 +809,11 @@ static bool pro_fusable(const mg3d_ctx *ctx, int iters, int want_res, int level)
     const int up_max = ctx->opt.v[MG3D_OPT_FUSE_UP_MAX] > ctx->opt.v[MG3D_OPT_FUSE_LEG_MAX] ? ctx->opt.v[MG3D_OPT_FUSE_UP_MAX]
                                                                                              : ctx->opt.v[MG3D_OPT_FUSE_LEG_MAX];
     const bool small = ctx->lv[level].g.N <= up_max && 2 * iters == 4 && want_res == 0;
-    /* On a 4-pass first launch of a level above small_max it is bit-identical but SLOWER (the four-row shape spills; round
-     * 2 measured 1.48 ms against 0.85 + 0.56 at 513^3): only where fuse_up_max asks for it.  The 2-pass first launch of a
-     * split stage takes it almost for free. */
+    /* On a 4-pass first launch of a level above small_max it used to be SLOWER (the four-row shape spilt; round 2 measured
+     * 1.48 ms against 0.85 + 0.56 at 513^3).  Since the prolongation is applied at the end of the step before (MG3D_PRO_LATE in
+     * the kernel) that shape has 248 VGPRs and no scratch: the 257^3 level of the 513^3 problem takes 0.12 instead of
+     * 0.058 + 0.112 ms, the cycle 2.18 -> 2.13 ms -- fuse_up_max now defaults to every level.  The 2-pass first launch of
+     * a split stage takes it almost for free. */
     if (!ctx->fused || iters < 1)
         return false;
     const bool sp = split_up_leg(iters, want_res);
@@ -943,7 +945,7 @@ extern "C" int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm)
  * cycle's own u is the up-leg's output: nothing is speculative inside mg3d_vcycles.  Behind a single mg3d_vcycle call
  * the next cycle's down-leg runs at once, into the alt buffers (u of the top level, d of the level below), so that the
  * norm is complete when the call returns; whatever the caller does instead of another cycle swaps back
- * (mg3d_drop_carry: no launch).  Same conditions as the carried cycles.  Default from 450 points per side (option
+ * (mg3d_drop_carry: no launch).  Same conditions as the carried cycles.  Default from 160 points per side (option
  * legs_min): same-box A/B by size, round 4 (ms per cycle, carried / legs): 385^3 1.23 / 1.30, 513^3 2.53 / 2.45, 641^3 4.99 / 4.80,
  * 769^3 11.31 / 10.76, 1025^3 20.65 / 16.79 (profiles/r04_legs_by_size.txt); option legs = 0 keeps the carried cycles. */
 bool mg3d_can_legs(const mg3d_ctx *ctx, int q)

@@ -56,7 +56,7 @@ enum {
     MG3D_OPT_CARRY = 0,    /* consecutive V(2,2) cycles share a launch on the finest level ("carried cycles") */
     MG3D_OPT_CARRY_MIN,    /* ... from this many points per side (130) */
     MG3D_OPT_LEGS,         /* one launch per leg on the finest level instead (round 4; 1) */
-    MG3D_OPT_LEGS_MIN,     /* ... from this many points per side (450: below it the carried cycles are faster) */
+    MG3D_OPT_LEGS_MIN,     /* ... from this many points per side (160: at 129^3 the carried cycles are 6 % faster, from 193^3 the legs win 3 - 24 %) */
     MG3D_OPT_TINY,         /* the level above the coarsest one in one workgroup */
     MG3D_OPT_TINY_CYCLE,   /* ... together with the direct solve in ONE launch */
     MG3D_OPT_LU_REDUCED,   /* install the factor without its identity rows beside the full one */

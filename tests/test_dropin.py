@@ -246,7 +246,7 @@ def test_reference_test_mg_3d_fmg_start(tmp_path, c, L, nu):
 def test_reference_test_mg_3d_129_cubed(tmp_path, monkeypatch, schedule):
     """BASELINE configs[1]: `9 5 2` = 129^3, V(2,2), through the unchanged reference driver.  "carried": the solve
     loop's cycles run ahead into each other (carried cycles, the default from 130 to 449 points per side); "legs": one
-    launch per leg with the next cycle's down-leg run ahead behind every SolverLinSolve (the default from 450 points per
+    launch per leg with the next cycle's down-leg run ahead behind every SolverLinSolve (the default from 160 points per
     side) -- same history, same error norm: the final SolverGetDetails / error check sees the finished cycle's own u."""
     if not os.path.exists(BIN1):
         pytest.skip("oracle/_ref/dropin_test_mg_3d was not built")

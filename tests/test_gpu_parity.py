@@ -413,9 +413,9 @@ def test_on_the_fly_restriction_equals_materialised_residual(c, L, nu):
 @pytest.mark.parametrize("c,L,nu", [(5, 5, 2), (9, 4, 1), (5, 4, 3), (3, 6, 2), (9, 5, 2)])
 def test_prolongation_fused_into_smoother_equals_separate_launch(c, L, nu, monkeypatch):
     """Option fuse_up_max (here through its environment override, read when the context is created) folds
-    prolongateAndCorrectError into the post-smoother's four-pass launch on every level (opt-in: measured slower above
-    the two-row shapes); by default it is its own kernel below the top level.  Same bits either way (and both equal the
-    oracle, see the history tests)."""
+    prolongateAndCorrectError into the post-smoother's four-pass launch on every level (the default since the
+    prolonging four-row shape runs without scratch, round 4); with 0 it is its own kernel below the top level.  Same bits
+    either way (and both equal the oracle, see the history tests)."""
     import subprocess, sys, json
     outs = []
     for flag in ("0", "1"):
@@ -922,7 +922,7 @@ def test_options_are_per_context_and_set_through_the_api(monkeypatch):
     monkeypatch.setenv("MG3D_CARRY_MIN", "66")
     with M.Solver(9, 5, 2) as a, M.Solver(9, 5, 2) as b:
         assert a.get_option("carry") == 1 and a.get_option("carry_min") == 66
-        assert a.get_option("legs") == 1 and a.get_option("legs_min") == 450  # (129^3 < 450: the carried cycles run here)
+        assert a.get_option("legs") == 1 and a.get_option("legs_min") == 160  # (129^3 < 160: the carried cycles run here)
         assert set(a.options()) >= {"carry", "carry_min", "legs", "legs_min", "tiny", "tiny_cycle", "lu_reduced", "fuse_rst2",
                                     "small_max", "fuse_leg_max", "fuse_up_max", "sweep_tune", "sweep_ci"}
         monkeypatch.setenv("MG3D_NO_CARRY", "1")  # after creation: nobody reads it any more
