@@ -476,7 +476,7 @@ static int sweep_impl(const mg3d_options &o, const Geom &g, const double *vin, c
 #define MG3D_LEG_UP_RJ 4
 #endif
 #ifndef MG3D_LEG_DP_UP
-#define MG3D_LEG_DP_UP (MG3D_LEG_UP_RJ == 4 ? 2 : 3)
+#define MG3D_LEG_DP_UP (MG3D_LEG_UP_RJ == 4 ? 0 : 3) /* four rows: 253 VGPRs with nothing parked; same-box A/B 0.716 (0) / 0.740 (1) / 0.729-0.743 ms (2) */
 #endif
 /* the down-leg's shape: four rows a thread, eight waves (two waves per SIMD: two slots of the d window parked in LDS, which the
  * single copy of the wave-edge rows -- EXS in the kernel -- makes room for) or eight rows, four waves (one wave per SIMD) */
@@ -574,3 +574,10 @@ int k_sweep_tap(const mg3d_options &o, const Geom &g, const double *vin, const d
     return sweep_impl(o, g, vin, d, vout, nullptr, partials, max_partials, h, 4, c1, false, s, acc_lo, acc_hi, nullptr, nullptr,
                       -1, -1, nullptr, nullptr, i_lo, i_hi, true, edge);
 }
+
+#ifdef MG3D_DEBUG_BLOCKTIMES
+extern "C" int mg3d_debug_blocktimes(unsigned long long *out) /* 8 x 1024 wall-clock samples (100 MHz ticks) of the last launch of the chosen shape */
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_bt), sizeof(unsigned long long) * 8 * 1024) == hipSuccess ? 0 : -1;
+}
+#endif

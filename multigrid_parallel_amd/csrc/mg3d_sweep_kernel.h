@@ -164,6 +164,12 @@ __device__ __forceinline__ void st_stream(double *p, double2 o)
 #ifndef MG3D_STAGE_MAJOR
 #define MG3D_STAGE_MAJOR 1 /* rows of a one-wave-per-SIMD thread whose stage chains are interleaved in the source (1: row-major).  Same-box A/B at 513^3, round 4: 1 -> 2.450, 2 -> 2.466, 4 -> 2.811 ms per cycle (the scheduler re-orders either way; wider groups only add AGPR traffic) */
 #endif
+#ifdef MG3D_DEBUG_BLOCKTIMES /* measurement builds only (tools/blocktimes.py): wall clock of every block of the chosen shape at five points of its march */
+__device__ unsigned long long g_dbg_bt[8][1024];
+#ifndef MG3D_DEBUG_BT_COND
+#define MG3D_DEBUG_BT_COND (PRO && S == 4 && TAP == 4)
+#endif
+#endif
 template <int S, int RES, int RJ, int NW, int PF, bool PRO, bool RST, int DP, int TAP, int C1K = -1>
 __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepArgs a)
 {
@@ -956,6 +962,11 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
 
     int pl = 0;
     for (; pl + 1 < nsteps; pl += 2) {
+#ifdef MG3D_DEBUG_BLOCKTIMES
+        if constexpr (MG3D_DEBUG_BT_COND)
+            if (threadIdx.x == 0 && blockIdx.x < 1024 && (pl & 31) == 0 && pl < 256)
+                g_dbg_bt[pl >> 5][blockIdx.x] = wall_clock64();
+#endif
         step(pl, std::integral_constant<int, 0>{});
         step(pl + 1, std::integral_constant<int, 1>{});
     }
