@@ -528,12 +528,12 @@ def main():
         if not is_carried:
             carried = timed_with({"legs": 0, "carry": 1, "carry_min": min(N_min_carry, N)},
                                  "options legs = 0, carry = 1: consecutive cycles share a launch (three memory-bound launches per "
-                                 "cycle on the finest level, 10.0 GB compulsory; the default below 450 points per side)")
+                                 "cycle on the finest level, 10.0 GB compulsory; the default below the option legs_min)")
         if not is_legs:
             legs = timed_with({"legs": 1, "legs_min": min(N_min_legs, N)},
                               "option legs = 1: ONE launch per leg on the finest level -- prolongation + four passes, three passes + "
                               "residual + restriction, the norm's halves taken from either side; 6.75 GB compulsory per cycle "
-                              "instead of 10.0, at one wave per SIMD (issue-bound; the default from 450 points per side)")
+                              "instead of 10.0, both launches at two waves per SIMD (the default from the option legs_min, 160 points per side)")
     fin = L - 1
     n_f = N ** 3
 
@@ -613,12 +613,13 @@ def main():
     if pmc_note:
         roof["traffic_note"] = pmc_note
     if any(r["kernel"] == "leg_up" for r in launches_tab):
-        roof["schedule_note"] = ("one launch per leg (default from 450 points per side): the finest level streams through the chip twice "
-                                 "per cycle instead of three times (6.75 instead of 10.0 GB compulsory, 7.8 instead of 11.4 GB HBM-side); "
-                                 "its two launches hold six-plane windows, which only fit at one wave per SIMD, where a step is bound "
-                                 "by instruction issue, not by bytes -- hence a LOWER per-launch fraction of the HBM roofline than the "
-                                 "carried schedule's memory-bound launches (0.60-0.65, see carried_schedule: same bits, a 3-5 % slower "
-                                 "cycle) for a FASTER cycle; vcycle_frac_of_hbm_peak is the figure that improves")
+        roof["schedule_note"] = ("one launch per leg (default from 160 points per side): the finest level streams through the chip twice "
+                                 "per cycle instead of three times (6.75 instead of 10.0 GB compulsory, 7.8 instead of 11.4 GB HBM-side). "
+                                 "Both launches run at two waves per SIMD since the prolongation is applied at the end of the previous "
+                                 "step (up-leg) and the wave-edge rows keep one LDS copy, which makes room to park two slots of the d "
+                                 "window (down-leg); the first version of round 4 needed one wave per SIMD and was bound by instruction "
+                                 "issue (0.88 + 1.03 ms against 0.72 + 0.85 now).  See carried_schedule / plain_schedule for the same "
+                                 "bits with three / four launches per cycle")
     # cycles of the timed region that carried the markers: all of them (--breakdown, mode 3) or every (mode - 2)-th
     tmode = 1 if args.breakdown else args.timing_mode
     sampled = args.steps if tmode < 4 else len(range(0, args.steps, tmode - 2))
