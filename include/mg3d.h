@@ -223,6 +223,8 @@ int mg3d_dist_comm_info(const mg3d_dist *d, int *rccl_ranks, int *overlap, int *
 int mg3d_dist_first_level(const mg3d_dist *d); /* lowest distributed level */
 int mg3d_dist_halo(const mg3d_dist *d);        /* halo planes per side */
 int mg3d_dist_carried_cycles(const mg3d_dist *d); /* cycles since creation that ended ahead into the next one ("carried cycles") */
+int mg3d_dist_legs_cycles(const mg3d_dist *d);    /* cycles since creation whose up-leg on the finest level ran as ONE launch (options legs, legs_min;
+                                                   * plan policy bits 4 / 8 of mg3d_dist_plan): their norm is completed by the next cycle's down-leg */
 int mg3d_dist_build_coarse(mg3d_dist *d, double h_coarse);
 int mg3d_dist_set_keep_residual(mg3d_dist *d, int keep); /* as mg3d_ctx_set_keep_residual */
 int mg3d_dist_set_option(mg3d_dist *d, const char *key, int value); /* as mg3d_ctx_set_option, for every local rank */
@@ -246,7 +248,10 @@ int mg3d_slab_owned(int coarse_pts, int num_levels, int nranks, int halo, int le
  * replicated level's arrays.  stream: 0 compute stream (overlap off); overlap on: every exchange is issued on the
  * communication stream, the only stream that drives the one communicator -- 1 the compute stream joins at once, 2 it joins
  * when it next needs the field (the transfer runs underneath the launches in between).  policy bit 0: the coarse levels are solved on rank 0 only (right-hand side gathered,
- * correction broadcast: MG3D_COARSE_GATHER=1) instead of replicated on every rank behind one all-gather. */
+ * correction broadcast: MG3D_COARSE_GATHER=1) instead of replicated on every rank behind one all-gather.  Bit 1 (2): a V(2,2) cycle that
+ * ends ahead into the next one ("carried cycles": HALO_U_NEXT brings three planes).  Bit 2 (4): a V(2,2) cycle whose up-leg on the
+ * finest level is ONE launch (HALO_U_NEXT brings planes 1..5, no NORM phase at the end: the next cycle's one-launch down-leg
+ * completes the norm); bit 3 (8): the cycle behind such a one (a NORM phase first, behind its down-leg).  8 alone: the last of a run. */
 enum { MG3D_XK_HALO_U_DOWN = 0, /* u_l after pre-smoothing + restriction, for the prolongation on the way up */
        MG3D_XK_HALO_D,          /* d_(l-1) after restriction */
        MG3D_XK_RHS_ALLGATHER,   /* d of the first replicated level: one broadcast per owner */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "mg3d_dist_first_level": (C.c_int, [C.c_void_p]),
     "mg3d_dist_halo": (C.c_int, [C.c_void_p]),
     "mg3d_dist_carried_cycles": (C.c_int, [C.c_void_p]),
+    "mg3d_dist_legs_cycles": (C.c_int, [C.c_void_p]),
     "mg3d_dist_set_keep_residual": (C.c_int, [C.c_void_p, C.c_int]),
     "mg3d_dist_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "mg3d_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
@@ -424,6 +425,9 @@ class DistSolver:
 
     def carried_cycles(self):
         return self.L.mg3d_dist_carried_cycles(self._h)
+
+    def legs_cycles(self):
+        return self.L.mg3d_dist_legs_cycles(self._h)
 
     def comm_info(self):
         """(ranks in the RCCL communicator, overlap on/off, HIP device)"""

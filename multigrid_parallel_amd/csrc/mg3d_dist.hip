@@ -122,6 +122,10 @@ static int build_plan(Plan &pl, int c, int L, int P, int nu, int rank, int overl
     const int lc = G.ld - 1, Nc = ((c - 1) << lc) + 1;
     const long long pec = plan_plane_elems(G, Nc);
     const int cs = overlap ? 1 : 0;
+    /* policy bit 3 (8): the cycle before this one ended with the one-launch up-leg (bit 2), which forms only the red half of
+     * its residual norm; the black half falls out of this cycle's one-launch down-leg, and the norm is reduced behind it */
+    if ((policy & 8) && nu == 2)
+        plan_norm(pl, G, L - 1, rank);
     for (int l = L - 1; l >= G.ld; l--) { /* down */
         /* first what the coarser level waits for (its right-hand side), then the large u exchange that hides underneath the
          * coarser levels: with ONE communicator, driven from one in-order stream, the issue order is the execution order */
@@ -154,13 +158,18 @@ static int build_plan(Plan &pl, int c, int L, int P, int nu, int rank, int overl
             /* policy bit 1: the cycle is carried into the next one (csrc/mg3d_ctx.hip "carried cycles", V(2,2) only): its
              * last launch has used up every halo plane and already holds three of the next cycle's pre-smoothing passes;
              * the one launch left of that down-leg (one pass + residual + restriction) reads three planes either side */
-            if ((policy & 2) && nu == 2)
+            /* policy bit 2 (4): one launch per leg (csrc/mg3d_ctx.hip, "one launch per leg"): the up-leg's one launch writes
+             * the owned planes only; the next cycle's down-leg (three passes + residual + restriction) reads five either side */
+            if ((policy & 4) && nu == 2)
+                plan_halo(pl, G, MG3D_XK_HALO_U_NEXT, MG3D_U, l, rank, 0, cs, 5);
+            else if ((policy & 2) && nu == 2)
                 plan_halo(pl, G, MG3D_XK_HALO_U_NEXT, MG3D_U, l, rank, 0, cs, 3);
             else
                 plan_halo(pl, G, MG3D_XK_HALO_U_NEXT, MG3D_U, l, rank, 1, cs);
         }
     }
-    plan_norm(pl, G, L - 1, rank);
+    if (!((policy & 4) && nu == 2)) /* (bit 2: this cycle's norm is completed and reduced by the next cycle) */
+        plan_norm(pl, G, L - 1, rank);
     pl.begin.push_back((int)pl.e.size());
     /* stream: 0 the compute stream (overlap off: every exchange sits where the schedule issues it); overlap on: EVERY
      * exchange is issued on the communication stream with the one communicator -- 1: the compute stream joins at once
@@ -193,6 +202,7 @@ struct SlabLevel {
 };
 
 struct RankState {
+    int legs_npa = 0; /* partial sums the one-launch up-leg has left in coarse->partials */
     int rank;
     std::vector<SlabLevel> dl; /* distributed levels ld .. L-1, index l - ld */
     mg3d_ctx *coarse;          /* replicated levels 0 .. ld-1 */
@@ -222,6 +232,11 @@ struct mg3d_dist {
      * entry and hold no plane arithmetic of their own */
     std::vector<Plan> plans;       /* one cycle on its own */
     std::vector<Plan> plans_carry; /* a cycle that ends ahead into the next one (policy bit 1) */
+    std::vector<Plan> plans_legs[3]; /* one launch per leg: a cycle whose up-leg is one launch (policy | 4), one between two such
+                                      * (| 12), the one that only completes its predecessor's norm (| 8) */
+    bool legs_pending;             /* the last cycle's norm is half formed (red half in every rank's partials[0 .. legs_npa)) */
+    bool legs_fixed, legs_on;      /* as carry_fixed / carry_on: agreed between the ranks of an RCCL job at creation */
+    int n_legs;                    /* cycles whose up-leg ran as one launch (mg3d_dist_legs_cycles) */
     const std::vector<Plan> *cur;  /* the plan of the cycle being enqueued */
     bool carried;                  /* u of the top level holds three pre-smoothing passes of the next cycle */
     /* a call failed after a cycle of it had carried: u of the top level is three passes into a cycle nobody finished and
@@ -311,6 +326,7 @@ __global__ void sum_in_order_kernel(const double *__restrict__ parts, int n, dou
 }
 
 static bool dist_carry_policy(mg3d_dist *D);
+static bool dist_legs_policy(mg3d_dist *D);
 static int dist_refuse_poisoned(const mg3d_dist *D, const char *who);
 
 extern "C" int mg3d_comm_unique_id(void *out128)
@@ -538,19 +554,30 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
     for (size_t ri = 0; ri < D->rs.size(); ri++)
         (void)build_plan(D->plans_carry[ri], coarse_pts, num_levels, nranks, smooth_iters, D->rs[ri].rank, D->overlap ? 1 : 0,
                          D->policy | 2); /* same arguments as above: cannot fail where that did not */
+    static const int legs_bits[3] = {4, 12, 8};
+    for (int v = 0; v < 3; v++) {
+        D->plans_legs[v].resize(D->rs.size());
+        for (size_t ri = 0; ri < D->rs.size(); ri++)
+            (void)build_plan(D->plans_legs[v][ri], coarse_pts, num_levels, nranks, smooth_iters, D->rs[ri].rank, D->overlap ? 1 : 0,
+                             D->policy | legs_bits[v]);
+    }
     D->cur = &D->plans;
     D->carried = false;
     D->poisoned = false;
     D->n_carried = 0;
     D->carry_fixed = false;
     D->carry_on = false;
+    D->legs_pending = false;
+    D->legs_fixed = false;
+    D->legs_on = false;
+    D->n_legs = 0;
     if (D->have_comm && nranks > 1) {
-        /* every rank must pick the same plan variant: all-reduce MIN of "carried cycles are on here" */
-        int mine = dist_carry_policy(D) ? 1 : 0, *dflag = nullptr;
-        bool ok = hipMalloc(&dflag, sizeof(int)) == hipSuccess &&
-                  hipMemcpyAsync(dflag, &mine, sizeof(int), hipMemcpyHostToDevice, D->stream) == hipSuccess &&
-                  ncclAllReduce(dflag, dflag, 1, ncclInt, ncclMin, D->comm, D->stream) == ncclSuccess &&
-                  hipMemcpyAsync(&mine, dflag, sizeof(int), hipMemcpyDeviceToHost, D->stream) == hipSuccess &&
+        /* every rank must pick the same plan variant: all-reduce MIN of "carried cycles are on here", "one launch per leg is" */
+        int mine[2] = {dist_carry_policy(D) ? 1 : 0, dist_legs_policy(D) ? 1 : 0}, *dflag = nullptr;
+        bool ok = hipMalloc(&dflag, sizeof(mine)) == hipSuccess &&
+                  hipMemcpyAsync(dflag, mine, sizeof(mine), hipMemcpyHostToDevice, D->stream) == hipSuccess &&
+                  ncclAllReduce(dflag, dflag, 2, ncclInt, ncclMin, D->comm, D->stream) == ncclSuccess &&
+                  hipMemcpyAsync(mine, dflag, sizeof(mine), hipMemcpyDeviceToHost, D->stream) == hipSuccess &&
                   hipStreamSynchronize(D->stream) == hipSuccess;
         if (dflag)
             (void)hipFree(dflag);
@@ -559,7 +586,9 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
             return fail(MG3D_ERR_HIP, "mg3d_dist_create: the ranks could not agree on the cycle schedule (all-reduce failed)");
         }
         D->carry_fixed = true;
-        D->carry_on = mine != 0;
+        D->carry_on = mine[0] != 0;
+        D->legs_fixed = true;
+        D->legs_on = mine[1] != 0;
     }
     *out = D;
     return MG3D_OK;
@@ -614,6 +643,7 @@ extern "C" int mg3d_dist_comm_info(const mg3d_dist *D, int *rccl_ranks, int *ove
 extern "C" int mg3d_dist_first_level(const mg3d_dist *D) { return D ? D->ld : -1; }
 extern "C" int mg3d_dist_halo(const mg3d_dist *D) { return D ? D->H : -1; }
 extern "C" int mg3d_dist_carried_cycles(const mg3d_dist *D) { return D ? D->n_carried : -1; }
+extern "C" int mg3d_dist_legs_cycles(const mg3d_dist *D) { return D ? D->n_legs : -1; }
 
 /* launch / schedule policy by key (mg3d_ctx_set_option) for every local rank.  carry / carry_min of a multi-rank RCCL job
  * are fixed when the handle is created (the ranks agree there) and refuse to change. */
@@ -624,9 +654,9 @@ extern "C" int mg3d_dist_set_option(mg3d_dist *D, const char *key, int value)
     const int i = mg3d_option_index(key);
     if (i < 0)
         return fail(MG3D_ERR_ARG, "mg3d_dist_set_option: no option \"%s\"", key ? key : "(null)");
-    if (D->carry_fixed && (i == MG3D_OPT_CARRY || i == MG3D_OPT_CARRY_MIN))
+    if ((D->carry_fixed && (i == MG3D_OPT_CARRY || i == MG3D_OPT_CARRY_MIN)) || (D->legs_fixed && (i == MG3D_OPT_LEGS || i == MG3D_OPT_LEGS_MIN)))
         return fail(MG3D_ERR_STATE, "mg3d_dist_set_option: %s is agreed between the ranks at creation", key);
-    if (D->carried)
+    if (D->carried || D->legs_pending)
         return fail(MG3D_ERR_STATE, "mg3d_dist_set_option: inside a carried cycle");
     for (auto &R : D->rs)
         CHK(mg3d_ctx_set_option(R.coarse, key, value));
@@ -993,6 +1023,23 @@ static bool dist_carry_policy(mg3d_dist *D) /* what the options say (carry, carr
     return o.v[MG3D_OPT_CARRY] != 0 && g.N >= o.v[MG3D_OPT_CARRY_MIN];
 }
 
+/* one launch per leg on slabs (csrc/mg3d_ctx.hip "one launch per leg"; options legs, legs_min): same conditions as the carried
+ * cycles, which it replaces where both apply */
+static bool dist_legs_policy(mg3d_dist *D)
+{
+    const mg3d_options &o = D->rs[0].coarse->opt;
+    const Geom &g = SL(D, D->rs[0], D->L - 1).lv.g;
+    return o.v[MG3D_OPT_LEGS] != 0 && g.N >= o.v[MG3D_OPT_LEGS_MIN];
+}
+
+static bool dist_can_legs(mg3d_dist *D)
+{
+    if (!(D->legs_fixed ? D->legs_on : dist_legs_policy(D)))
+        return false;
+    const Geom &g = SL(D, D->rs[0], D->L - 1).lv.g;
+    return D->nu == 2 && D->H >= 5 && !D->rs[0].coarse->keep_r && g.N > 65 && (g.nj & 1) != 0;
+}
+
 static bool dist_can_carry(mg3d_dist *D)
 {
     if (!(D->carry_fixed ? D->carry_on : dist_carry_policy(D)))
@@ -1009,19 +1056,25 @@ static int dist_refuse_poisoned(const mg3d_dist *D, const char *who)
     return MG3D_OK;
 }
 
-static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false)
+/* carry_out: another cycle of this call follows (it may be enqueued ahead into); legs_out: it follows in the same batch of norm
+ * slots (its down-leg completes this cycle's norm into slot `slot`, which the batch then reads back) */
+static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false, bool legs_out = false)
 {
     hipStream_t s = D->stream;
     const int L = D->L, ld = D->ld;
     D->phase = 0;
-    const bool can = dist_can_carry(D), carry_in = D->carried;
-    if (carry_in && !can) {
+    const bool can_legs = dist_can_legs(D), legs_in = D->legs_pending;
+    const bool can = !can_legs && dist_can_carry(D), carry_in = D->carried;
+    if ((carry_in && !can) || (legs_in && (!can_legs || slot < 1))) {
         D->carried = false;
+        D->legs_pending = false;
         return fail(MG3D_ERR_STATE, "mg3d_dist_vcycles: carried state met a cycle that cannot continue it");
     }
     carry_out = carry_out && can;
-    D->cur = carry_out ? &D->plans_carry : &D->plans;
+    legs_out = legs_out && can_legs;
+    D->cur = legs_out ? &D->plans_legs[legs_in ? 1 : 0] : legs_in ? &D->plans_legs[2] : carry_out ? &D->plans_carry : &D->plans;
     D->carried = false;
+    D->legs_pending = false;
     DistScope cycle_timer(D, 0, s);
     if (D->timing)
         D->t_cycles++;
@@ -1056,7 +1109,28 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false)
         const bool keep = D->rs[0].coarse->keep_r;
         std::vector<RestrictTarget> none(D->rs.size(), RestrictTarget{nullptr, nullptr, -1, -1});
         CHK(await_u(D, l));
-        if (l == L - 1 && carry_in) {
+        if (l == L - 1 && legs_in) {
+            /* the down-leg as ONE launch over the owned planes: three passes (black first -- the cycle's first red pass is the
+             * identity behind the previous cycle's last one), residual, restriction; it reads five planes either side, which
+             * the previous cycle's last exchange refreshed.  On its way it forms the black half of the previous cycle's
+             * residual norm, whose red half the one-launch up-leg left in partials[0 .. legs_npa): folded and reduced here. */
+            for (size_t ri = 0; ri < D->rs.size(); ri++) {
+                RankState &R = D->rs[ri];
+                SlabLevel &sl = SL(D, R, l);
+                Level &lv = sl.lv;
+                mg3d_ctx *cx = R.coarse;
+                double *part_b = cx->partials + MG3D_MAX_PARTIALS / 2;
+                const int npb = k_sweep_leg_down(cx->opt, lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt, *tgt[ri].gc, tgt[ri].dc, lv.h, 3, part_b,
+                                                 MG3D_MAX_PARTIALS / 2, s, sl.own_lo, sl.own_hi, tgt[ri].lo, tgt[ri].hi, sl.own_lo, sl.own_hi);
+                if (npb <= 0)
+                    return fail(MG3D_ERR_STATE, "slab sweep: no kernel for the one-launch down-leg on level %d", l);
+                k_fold2(cx->partials, R.legs_npa, part_b, npb, cx->sumsq, s);
+                double *t = lv.f[MG3D_U];
+                lv.f[MG3D_U] = lv.alt;
+                lv.alt = t;
+            }
+            CHK(reduce_norm(D, slot - 1));
+        } else if (l == L - 1 && carry_in) {
             /* the one pre-smoothing pass that is left (black) + residual + restriction in one launch over the owned planes:
              * it reads three planes either side, which the previous cycle's last exchange refreshed */
             for (size_t ri = 0; ri < D->rs.size(); ri++) {
@@ -1113,7 +1187,11 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false)
             CHK(exchange(D, MG3D_XK_HALO_U_UP, l - 1, false));
         CHK(await_u(D, l));
         const int want = l == L - 1 ? 1 : 0;
-        const bool fold = dist_split_up_leg(D, 1, want);
+        /* the prolongation rides on the post-smoother's first launch: the top level's split stage, and (option fuse_up_max, as
+         * on a single domain) the four-pass launch of a V(2,2) cycle on the levels below it */
+        const Geom &gl = SL(D, D->rs[0], l).lv.g;
+        const bool fold = dist_split_up_leg(D, 1, want) ||
+                          (D->nu == 2 && want == 0 && (gl.nj & 1) != 0 && gl.N <= D->rs[0].coarse->opt.v[MG3D_OPT_FUSE_UP_MAX]);
         std::vector<ProlongSource> pro(D->rs.size());
         for (size_t ri = 0; ri < D->rs.size(); ri++) {
             RankState &R = D->rs[ri];
@@ -1127,13 +1205,58 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false)
          * 2*nu of them.  The next cycle's pre-smoother wants fresh halos on the finest u: that exchange starts
          * underneath the norm kernel, which reads the first halo plane on either side -- just produced
          * exactly by the post-smoother, so the exchange leaves that plane alone. */
+        if (l == L - 1 && legs_out) {
+            /* the up-leg as ONE launch: prolongation + four passes over the owned planes (it uses up four of the H halo planes of
+             * u and of the correction), the red half of the norm from the last pass's own sums.  With a communication stream the
+             * first and last five planes -- what the exchange for the next down-leg sends -- are made first, as one launch of two
+             * chunks per rank; the exchange then runs underneath the launch that makes the interior. */
+            const int E = 5;
+            bool edge_first = D->overlap && D->P > 1;
+            for (auto &R : D->rs)
+                edge_first = edge_first && SL(D, R, l).own_hi - SL(D, R, l).own_lo >= 2 * E + 2;
+            auto up = [&](size_t ri, const double *vin, double *vout, double *part, int maxp, int lo, int hi, int edge) -> int {
+                SlabLevel &sl = SL(D, D->rs[ri], l);
+                Level &lv = sl.lv;
+                return k_sweep_leg_up(D->rs[ri].coarse->opt, lv.g, vin, lv.f[MG3D_D], vout, *pro[ri].gc, pro[ri].ec, lv.h, part, maxp, s,
+                                      sl.own_lo, sl.own_hi, lo, hi, edge);
+            };
+            std::vector<int> n1(D->rs.size(), 0);
+            for (size_t ri = 0; ri < D->rs.size(); ri++) {
+                SlabLevel &sl = SL(D, D->rs[ri], l);
+                n1[ri] = up(ri, sl.lv.f[MG3D_U], sl.lv.alt, D->rs[ri].coarse->partials, MG3D_MAX_PARTIALS / 4, sl.own_lo, sl.own_hi, edge_first ? E : 0);
+                if (n1[ri] <= 0)
+                    return fail(MG3D_ERR_STATE, "slab sweep: no kernel for the one-launch up-leg on level %d", l);
+            }
+            for (auto &R : D->rs) { /* the exchange sends from (and lands in) the NEW buffer */
+                Level &lv = SL(D, R, l).lv;
+                double *t = lv.f[MG3D_U];
+                lv.f[MG3D_U] = lv.alt;
+                lv.alt = t;
+            }
+            CHK(start_u_exchange(D, MG3D_XK_HALO_U_NEXT, l));
+            for (size_t ri = 0; ri < D->rs.size(); ri++) {
+                SlabLevel &sl = SL(D, D->rs[ri], l);
+                int n2 = 0;
+                if (edge_first) {
+                    n2 = up(ri, sl.lv.alt, sl.lv.f[MG3D_U], D->rs[ri].coarse->partials + n1[ri], MG3D_MAX_PARTIALS / 2 - n1[ri], sl.own_lo + E,
+                            sl.own_hi - E, 0);
+                    if (n2 <= 0)
+                        return fail(MG3D_ERR_STATE, "slab sweep: no kernel for the interior of the one-launch up-leg on level %d", l);
+                }
+                D->rs[ri].legs_npa = n1[ri] + n2;
+            }
+            D->legs_pending = true;
+            D->n_legs++;
+            continue;
+        }
         CHK(stage_smooth(D, l, 1, want, nullptr, false, l == L - 1, fold ? pro.data() : nullptr, l == L - 1 && carry_out));
         if (l == L - 1 && carry_out) {
             D->carried = true;
             D->n_carried++;
         }
     }
-    CHK(reduce_norm(D, slot));
+    if (!legs_out)
+        CHK(reduce_norm(D, slot));
     if (D->phase != (int)(*D->cur)[0].kind.size())
         return fail(MG3D_ERR_STATE, "slab schedule ended after %d of the plan's %d phases", D->phase, (int)(*D->cur)[0].kind.size());
     hipError_t e = hipGetLastError();
@@ -1162,14 +1285,14 @@ extern "C" int mg3d_dist_vcycles(mg3d_dist *D, int count, double *norms)
             if (!ok && (d->carried || d->n_carried != before))
                 d->poisoned = true;
             if (!ok)
-                d->carried = false;
+                d->carried = false, d->legs_pending = false; /* (a half-formed norm is simply lost: u itself is a finished cycle's) */
         }
     } guard{D, carried_before, false};
     for (int done = 0; done < count;) {
         const int nb = (count - done < D->norm_slots) ? count - done : D->norm_slots;
         for (int c = 0; c < nb; c++) {
             /* every cycle but the last of a call ends ahead into the next one (a call never ends in the carried state) */
-            CHK(dist_enqueue_vcycle(D, c, done + c + 1 < count));
+            CHK(dist_enqueue_vcycle(D, c, done + c + 1 < count, c + 1 < nb));
         }
         CHK(dist_finish(D));
         HIPCHK(hipMemcpyAsync(D->h_norms, D->d_norms, nb * sizeof(double), hipMemcpyDeviceToHost, D->stream));

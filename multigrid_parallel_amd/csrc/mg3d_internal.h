@@ -129,7 +129,7 @@ int k_sweep_leg_down(const mg3d_options &o, const Geom &g, const double *vin, co
                      int ic_hi = -1, int i_lo = -1, int i_hi = -1);
 int k_sweep_leg_up(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, const Geom &gce, const double *ec, double h,
                    double *partials, int max_partials, hipStream_t s, int acc_lo = 0, int acc_hi = -1, int i_lo = -1,
-                   int i_hi = -1);
+                   int i_hi = -1, int edge = 0);
 /* mg3d_tiny.hip: the level above the coarsest one in one workgroup (LDS-resident), when it fits (N <= 17) */
 bool k_tiny_fits(const Geom &g, const Geom &gc);
 /* zero guess, `iters` x (red, black), residual, restriction (interior + face injection from r's boundary) into dc */

@@ -539,7 +539,7 @@ int k_sweep_leg_down(const mg3d_options &o, const Geom &g, const double *vin, co
 }
 
 int k_sweep_leg_up(const mg3d_options &o, const Geom &g, const double *vin, const double *d, double *vout, const Geom &gce, const double *ec, double h,
-                   double *partials, int max_partials, hipStream_t s, int acc_lo, int acc_hi, int i_lo, int i_hi)
+                   double *partials, int max_partials, hipStream_t s, int acc_lo, int acc_hi, int i_lo, int i_hi, int edge)
 {
     if ((g.nj & 1) == 0)
         return -1;
@@ -549,6 +549,7 @@ int k_sweep_leg_up(const mg3d_options &o, const Geom &g, const double *vin, cons
         return 0;
     a.ec = ec;
     a.gce = gce;
+    a.edge = edge;
 #if MG3D_LEG_UP_RJ == 4
     if (partials)
         return launch_sweep<4, 0, 4, 8, 1, true, true, MG3D_LEG_DP_UP, 4>(o, a, max_partials, s);

@@ -54,12 +54,14 @@ class PlanRunner:
     def __init__(self, c, L, P, nu, r, policy=0):
         self.plain = PL.phases(c, L, P, nu, r, 0, policy)
         self.carried = PL.phases(c, L, P, nu, r, 0, policy | 2)  # a cycle that ends ahead into the next one
+        # one launch per leg: a cycle that ends with the one-launch up-leg (4), one that follows such a cycle (8), both (12)
+        self.legs = {(i, o): PL.phases(c, L, P, nu, r, 0, policy | (8 if i else 0) | (4 if o else 0)) for i in (0, 1) for o in (0, 1)}
         self.ph = self.plain
         self.r, self.cur = r, 0
 
-    def start_cycle(self, carry_out=False):
+    def start_cycle(self, carry_out=False, legs_in=False, legs_out=False):
         self.cur = 0
-        self.ph = self.carried if carry_out else self.plain
+        self.ph = self.legs[(int(legs_in), int(legs_out))] if (legs_in or legs_out) else self.carried if carry_out else self.plain
 
     def run(self, kind, level, array_of, norm_part=None):
         """next phase of the cycle; array_of(field, level) -> the (planes, N, N) array the entries index"""
@@ -96,7 +98,7 @@ class PlanRunner:
         return gathered
 
 
-def worker(r, P, port, c, L, nu, cycles, out_path, policy=0, carry=False):
+def worker(r, P, port, c, L, nu, cycles, out_path, policy=0, carry=False, legs=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=r, world_size=P)
     lib = M.lib()
@@ -129,15 +131,27 @@ def worker(r, P, port, c, L, nu, cycles, out_path, policy=0, carry=False):
         return (Hc.u if field == 0 else Hc.d)[level].reshape(Ncr, Ncr, Ncr)
 
     carried = False  # u of the top level already holds the next cycle's first three pre-smoothing passes
+    pending = None   # one launch per leg: the previous cycle's sum of squares, reduced behind this cycle's down-leg
     for cyc in range(cycles):
         # carried cycles (V(2,2); csrc/mg3d_dist.hip dist_enqueue_vcycle): every cycle but the last ends ahead
         carry_in, carry_out = carried, carry and nu == 2 and cyc + 1 < cycles
-        plan.start_cycle(carry_out)
+        # one launch per leg: every cycle but the last ends with the one-launch up-leg, whose norm the next cycle completes
+        legs_in, legs_out = pending is not None, legs and nu == 2 and cyc + 1 < cycles
+        plan.start_cycle(carry_out, legs_in, legs_out)
         for l in range(L - 1, ld - 1, -1):  # ---- down
             sl = lv[l]
             if l < L - 1:
                 sl.u[:] = 0.0
-            if l == L - 1 and carry_in:
+            if l == L - 1 and legs_in:
+                # the down-leg in one launch: the cycle's first red pass is the identity behind the previous cycle's last one
+                # (checked here, skipped on the GPU); black, red, black are left.  It reads five planes either side.
+                before = sl.u.copy()
+                S.colour_pass(sl.u, sl.d, hs[l], 1, sl.ig0, sl.N)
+                assert np.array_equal(sl.u[sl.own_lo:sl.own_hi], before[sl.own_lo:sl.own_hi]), "red behind red: the identity"
+                sl.u[:] = before
+                for colour in (0, 1, 0):
+                    S.colour_pass(sl.u, sl.d, hs[l], colour, sl.ig0, sl.N)
+            elif l == L - 1 and carry_in:
                 S.colour_pass(sl.u, sl.d, hs[l], 0, sl.ig0, sl.N)  # the one pre-smoothing pass that is left: black
             else:
                 S.smooth(sl.u, sl.d, hs[l], nu, False, sl.ig0, sl.N)
@@ -149,6 +163,10 @@ def worker(r, P, port, c, L, nu, cycles, out_path, policy=0, carry=False):
                 dc = Hc.d[ld - 1].reshape(Ncr, Ncr, Ncr)
                 flo, fhi = owned(c, L, P, H, ld, r)
                 S.restrict_planes(sl.r, sl.ig0, sl.N, dc, 0, Ncr, 0 if r == 0 else flo // 2, Ncr if r == P - 1 else fhi // 2)
+            if l == L - 1 and legs_in:  # the previous cycle's norm, completed by the launch above
+                parts = plan.run(PL.NORM, L - 1, array_of, norm_part=pending)
+                norms.append(float(np.sqrt(sum(parts))))
+                pending = None
             # first what the coarser level waits for ...
             if l - 1 >= ld:
                 plan.run(PL.HALO_D, l - 1, array_of)
@@ -178,6 +196,20 @@ def worker(r, P, port, c, L, nu, cycles, out_path, policy=0, carry=False):
         # on the GPU the exchange below runs underneath the norm kernel, which reads the first halo plane:
         # that plane is left as the post-smoother produced it (exact), planes 2..H are refreshed
         top_before = top.u.copy()
+        if legs_out:
+            # the one-launch up-leg wrote the owned planes only; five halo planes either side come by exchange for the next
+            # cycle's down-leg (the sixth stays stale until the exchange behind that launch).  No NORM phase: the sum of
+            # squares over the owned planes waits for the next cycle.
+            pending = S.residual(top_before, top.d, hs[L - 1], None, top.ig0, top.N, top.own_lo, top.own_hi)
+            top.u[:top.own_lo] = np.nan
+            top.u[top.own_hi:] = np.nan
+            plan.run(PL.HALO_U_NEXT, L - 1, array_of)
+            if top.own_lo:
+                assert np.isnan(top.u[:top.own_lo - 5]).all() and not np.isnan(top.u[top.own_lo - 5:top.own_lo]).any()
+            assert plan.cur == len(plan.ph), "the cycle used every phase of the plan"
+            stale = np.isnan(top.u)
+            top.u[stale] = top_before[stale]  # (stale, not poisoned: the next down-leg must not depend on them)
+            continue
         if carry_out:
             # the launch that took the norm went on: the next cycle's pre-smoothing passes red (the identity behind the
             # post-smoother's last red pass: checked here, skipped on the GPU), black, red -- every halo plane is used up,
@@ -217,12 +249,15 @@ def worker(r, P, port, c, L, nu, cycles, out_path, policy=0, carry=False):
     (5, 5, 2, 2, 16, 0, False), (5, 5, 1, 2, 8, 0, False), (3, 6, 2, 3, 8, 0, False), (3, 6, 2, 3, 16, 0, False),
     (5, 5, 2, 2, 16, 1, False), (3, 6, 2, 3, 8, 1, False),
     # carried cycles: the schedule of V(2,2) cycles that end ahead into the next one, its plan variant (policy | 2)
-    (5, 5, 2, 2, 16, 0, True), (3, 6, 2, 3, 8, 0, True), (3, 6, 2, 3, 8, 1, True)])
+    (5, 5, 2, 2, 16, 0, True), (3, 6, 2, 3, 8, 0, True), (3, 6, 2, 3, 8, 1, True),
+    # one launch per leg: the up-leg writes the owned planes only, five halo planes by exchange, the norm completed by the next
+    # cycle's down-leg (plan variants policy | 4, | 8, | 12)
+    (5, 5, 2, 2, 16, 0, "legs"), (3, 6, 2, 3, 8, 0, "legs"), (3, 6, 2, 3, 8, 1, "legs")])
 def test_slab_schedule_over_gloo(tmp_path, monkeypatch, c, L, nu, P, min_planes, policy, carry):
     monkeypatch.setenv("MG3D_SLAB_MIN_PLANES", str(min_planes))  # 8: thin slabs, three distributed levels
     cycles = 4 if carry else 3
     out = str(tmp_path / "res.npz")
-    mp.spawn(worker, args=(P, free_port(), c, L, nu, cycles, out, policy, carry), nprocs=P, join=True)
+    mp.spawn(worker, args=(P, free_port(), c, L, nu, cycles, out, policy, carry is True, carry == "legs"), nprocs=P, join=True)
     got = np.load(out)
     O.lib().orc_set_threads(1)
     want_norms, want_u, _, _ = O.run_problem(c, L, nu, cycles)

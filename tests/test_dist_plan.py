@@ -26,7 +26,9 @@ def slab(c, L, P, H, level, r):
     return dict(ig0=glo - h_lo, ni=ghi - glo + h_lo + h_hi, own_lo=h_lo, own_hi=h_lo + ghi - glo)
 
 
-@pytest.mark.parametrize("policy", [0, 1, 2, 3])  # bit 0: coarse levels on rank 0; bit 1: the cycle is carried into the next
+# bit 0: coarse levels on rank 0; bit 1: the cycle is carried into the next; bits 2 / 3: one launch per leg (the cycle ends with the
+# one-launch up-leg / follows such a cycle)
+@pytest.mark.parametrize("policy", [0, 1, 2, 3, 4, 8, 12, 13])
 @pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("P", [2, 3, 4, 8])
 @pytest.mark.parametrize("c,L,nu", CONFIGS)
@@ -97,7 +99,10 @@ def test_every_send_has_its_receive(c, L, nu, P, overlap, policy):
                 cover = b
             assert cover == Nc and all(e.op == PL.RECV for e in per[0])
         if kind == PL.NORM:
-            assert ph == nph - 1 and [[(e.op, e.offset, e.count) for e in es] for es in per] == [[(PL.ALLGATHER, r, 1)] for r in range(P)]
+            legs_in, legs_out = nu == 2 and bool(policy & 8), nu == 2 and bool(policy & 4)
+            # at the end of the cycle -- unless the next cycle completes it (bit 2); first of all behind such a cycle (bit 3)
+            assert ph in ([0] if legs_in else []) + ([] if legs_out else [nph - 1])
+            assert [[(e.op, e.offset, e.count) for e in es] for es in per] == [[(PL.ALLGATHER, r, 1)] for r in range(P)]
     assert sent == recvd > 0
 
 
@@ -228,3 +233,45 @@ def test_carried_cycle_plan_differs_only_in_the_last_u_exchange(c, L, nu, P):
                 assert b.offset == (sl["own_hi"] - 3 if b.peer == r + 1 else sl["own_lo"])
             else:  # the three halo planes next to the owned ones
                 assert b.offset == (sl["own_hi"] if b.peer == r + 1 else sl["own_lo"] - 3)
+
+
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
+@pytest.mark.parametrize("c,L,nu", CONFIGS)
+def test_one_launch_per_leg_plans(c, L, nu, P):
+    """policy bits 2 and 3 (V(2,2) cycles with one launch per leg on the finest level, csrc/mg3d_dist.hip): a cycle that ends with
+    the one-launch up-leg (4) exchanges halo planes 1..5 of the finest u -- that launch writes the owned planes only, the next
+    cycle's one-launch down-leg reads five either side -- and has no NORM phase of its own; the cycle behind it (8) opens with the
+    NORM phase of its predecessor.  Everything else is the plain plan, and for any other sweep count the bits change nothing."""
+    lib = M.lib()
+    H = lib.mg3d_slab_halo(nu)
+    ld = lib.mg3d_slab_first_level(c, L, P, H)
+    if ld >= L:
+        pytest.skip("no level gives every rank enough planes")
+    for r in range(P):
+        plain = PL.entries(c, L, P, nu, r, 0, 0)
+        if nu != 2:
+            assert all(PL.entries(c, L, P, nu, r, 0, pol) == plain for pol in (4, 8, 12))
+            continue
+        sl = slab(c, L, P, H, L - 1, r)
+        body = [e for e in plain if e.kind != PL.NORM]
+        norm = [e for e in plain if e.kind == PL.NORM]
+        for pol in (4, 8, 12):
+            got = PL.entries(c, L, P, nu, r, 0, pol)
+            shift = 1 if pol & 8 else 0
+            g_norm = [e for e in got if e.kind == PL.NORM]
+            g_body = [e for e in got if e.kind != PL.NORM]
+            want_norm_phases = ([0] if pol & 8 else []) + ([] if pol & 4 else [max(e.phase for e in plain) + shift])
+            assert [e.phase for e in g_norm] == want_norm_phases
+            assert all(e._replace(phase=0) == norm[0]._replace(phase=0) for e in g_norm)
+            assert len(g_body) == len(body)
+            for a, b in zip(body, g_body):
+                assert b.phase == a.phase + shift
+                if a.kind != PL.HALO_U_NEXT or not pol & 4:
+                    assert a._replace(phase=0) == b._replace(phase=0)
+                    continue
+                assert (a.op, a.peer, a.field, a.level, a.plane_elems, a.stream) == (b.op, b.peer, b.field, b.level, b.plane_elems, b.stream)
+                assert a.count == H - 1 and b.count == 5
+                if b.op == PL.SEND:  # the five owned planes next to the boundary the peer sits behind
+                    assert b.offset == (sl["own_hi"] - 5 if b.peer == r + 1 else sl["own_lo"])
+                else:  # the five halo planes next to the owned ones
+                    assert b.offset == (sl["own_hi"] if b.peer == r + 1 else sl["own_lo"] - 5)

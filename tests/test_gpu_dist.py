@@ -56,6 +56,7 @@ def test_slab_carried_cycles(monkeypatch, c, L, P, min_planes):
     and to the slab path's plain schedule bit for bit, also over several calls."""
     monkeypatch.setenv("MG3D_SLAB_MIN_PLANES", str(min_planes))
     monkeypatch.setenv("MG3D_CARRY_MIN", "66")
+    monkeypatch.setenv("MG3D_LEGS", "0")  # (from 160 points per side the one-launch legs would take the carried cycles' place)
     want_norms, want_u = single(c, L, 2, 7)
     res = []
     for flag in ("0", "1"):
@@ -71,6 +72,37 @@ def test_slab_carried_cycles(monkeypatch, c, L, P, min_planes):
         assert np.array_equal(a, b)
     np.testing.assert_allclose(res[0][0], want_norms, rtol=1e-11, atol=0)
     np.testing.assert_allclose(res[1][0], want_norms, rtol=1e-11, atol=0)
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+@pytest.mark.parametrize("c,L,P,min_planes", [(9, 5, 2, 16), (9, 5, 8, 16), (9, 5, 4, 8), (5, 6, 4, 8), (3, 7, 3, 16), (9, 6, 4, 16),
+                                              (9, 6, 8, 8), (9, 6, 2, 16)])
+def test_slab_one_launch_per_leg(monkeypatch, c, L, P, min_planes, overlap):
+    """One launch per leg on slabs (V(2,2); by default from 160 points per side -- the last three cases): every cycle but the last
+    of a batch ends with the one-launch up-leg over the owned planes (edge windows first when the exchanges have their own stream
+    and the slab is thick enough), the exchange behind it brings five halo planes (plan variant `policy | 4`), the next cycle's
+    down-leg is one launch that also completes the norm (`policy | 8`).  Equal to the single domain and to the slab path's plain
+    schedule bit for bit, also over several calls."""
+    monkeypatch.setenv("MG3D_SLAB_MIN_PLANES", str(min_planes))
+    monkeypatch.setenv("MG3D_LEGS_MIN", "66")
+    monkeypatch.setenv("MG3D_NO_OVERLAP", "0" if overlap == "1" else "1")
+    want_norms, want_u = single(c, L, 2, 7)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MG3D_LEGS", flag)
+        monkeypatch.setenv("MG3D_NO_CARRY", "1")
+        with M.DistSolver(c, L, 2, nranks=P) as d:
+            d.setup_test_problem()
+            norms = list(d.vcycles(4)) + list(d.vcycles(1)) + list(d.vcycles(2))
+            assert d.legs_cycles() == (4 if flag == "1" else 0) and d.carried_cycles() == 0  # 3 + 0 + 1
+            assert norms[-1] == pytest.approx(exact_norm(d, L), rel=EXACT_NORM_RTOL)
+            res.append((np.array(norms), d.download(MG3D_U, L - 1), [d.download(MG3D_U, l) for l in range(d.first_level, L - 1)]))
+    assert np.array_equal(res[0][1], want_u) and np.array_equal(res[1][1], want_u)
+    for a, b in zip(res[0][2], res[1][2]):
+        assert np.array_equal(a, b)
+    np.testing.assert_allclose(res[0][0], want_norms, rtol=1e-11, atol=0)
+    np.testing.assert_allclose(res[1][0], want_norms, rtol=1e-11, atol=0)
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-13, atol=0)
 
 
 @pytest.mark.parametrize("fuse", ["0", "1"])
