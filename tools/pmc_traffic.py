@@ -36,7 +36,7 @@ def load(d):
 A, B = load("pmc_fetch"), load("pmc_write")
 # (most specific first: the one-launch-per-leg shapes share their first template arguments with the four-row ones; bench.py's
 # default command runs the configured schedule, then option carry = 0, then option legs = 1, so all of them appear)
-timer_of = {"sweep_kernel<4, 0, 8, 4, 1, true": "leg_up", "sweep_kernel<3, 2, 8, 4,": "leg_down",
+timer_of = {"sweep_kernel<4, 0, 4, 8, 1, true, true, 0, 4": "leg_up", "sweep_kernel<3, 2, 4, 8,": "leg_down",
             "sweep_kernel<4, 3,": "sweep4+norm", "sweep_kernel<1, 2,": "sweep1+restrict", "sweep_kernel<4, 0, 4, 8, 1, false": "sweep4",
             "sweep_kernel<0, 2,": "residual", "sweep_kernel<2, 1,": "sweep2+residual", "sweep_kernel<2, 0,": "sweep2",
             "prolong_cell_kernel": "prolong"}
