@@ -39,7 +39,7 @@ for ch in range(2):
     grid = np.zeros((22, 5)); xcd = np.zeros((22, 5), dtype=int)
     for vb in range(ch * T, (ch + 1) * T):
         c, tl = tile_of(vb)
-        grid[tl // NTK, tl % NTK] = rate[vb]; xcd[tl // NTK, tl % NTK] = vb & 7
+        grid[tl % 22, tl // 22] = rate[vb]; xcd[tl % 22, tl // 22] = vb & 7  # tiles are numbered j-fastest (MG3D_TILE_J_FASTEST)
     print(f"chunk layer {ch}: us per step by tile (rows tj, columns tk) | XCD group")
     for j in range(22):
         print("  " + " ".join(f"{v:5.2f}" for v in grid[j]) + "   | " + " ".join(str(v) for v in xcd[j]))
