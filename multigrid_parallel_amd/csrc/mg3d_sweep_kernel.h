@@ -568,20 +568,6 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
         unsigned lm = lmask;
         asm volatile("" : "+v"(lm));
         /* current plane <- head of the prefetch queue, then request plane i+PF */
-#ifndef MG3D_PIN_LOADS
-#define MG3D_PIN_LOADS 0
-#endif
-        if constexpr (MG3D_PIN_LOADS != 0) {
-            /* The plane requested a step ago is first TOUCHED here, behind the barrier: an empty volatile asm that takes its
-             * registers.  Without it the scheduler hoists this step's first copies of those registers (plain VALU moves,
-             * free to cross an s_barrier) into the tail of the previous step, and the wait for the load goes with them:
-             * the listing showed `s_waitcnt vmcnt(7) .. (4)` strung through the step that had just issued the request --
-             * a plane was in flight for a fraction of a step, not for one. */
-            constexpr int SLOT = PF == 2 ? PAR : 0;
-#pragma unroll
-            for (int rr = 0; rr < RJ; rr++)
-                asm volatile("" : "+v"(nxt_v[SLOT][rr].x), "+v"(nxt_v[SLOT][rr].y), "+v"(nxt_d[SLOT][rr].x), "+v"(nxt_d[SLOT][rr].y));
-        }
         if constexpr (PF == 2) {
             /* two planes in flight as a RING indexed by the step's parity (a template argument), not a queue that shifts:
              * shifting copies the registers of the plane still in flight, and a copy has to wait for its load -- with
@@ -592,11 +578,7 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
                 dring[rr][0][0] = nxt_d[PAR][rr].x;
                 dring[rr][0][1] = nxt_d[PAR][rr].y;
             }
-#ifndef MG3D_PF2_LATE
-#define MG3D_PF2_LATE 0 /* 1: the ring's loads are issued at the END of the step, behind its stores (see there) */
-#endif
-            if constexpr (MG3D_PF2_LATE == 0)
-                load_plane(i + PF, nxt_v[PAR], nxt_d[PAR]);
+            load_plane(i + PF, nxt_v[PAR], nxt_d[PAR]);
         } else {
 #pragma unroll
             for (int rr = 0; rr < RJ; rr++) {
@@ -633,35 +615,6 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
             }
         }
 
-        /* DP > 0, MG3D_DP_PREFETCH: the parked d values this step's stages read, requested HERE -- a step's worth of LDS
-         * latency ahead of their first use -- instead of one ds_read in front of the multiply that needs it (24
-         * `s_waitcnt lgkmcnt(0)` a step in the listing, each right behind its read).  The scheduling barrier keeps the
-         * compiler from sinking them back.  Measured: no gain (see the switch). */
-#ifndef MG3D_DP_PREFETCH
-#define MG3D_DP_PREFETCH 0 /* same-box A/B at 513^3 (round 4): up-leg 0.872-0.882 ms with, 0.866-0.877 without; the down-leg spills
-                            * 44-72 bytes with it (1.02 / 1.15 ms for one / both slots ahead against 1.03): the waits the listing
-                            * shows are not where the time goes (tools/ilp_probe.hip: a dependent fp64 add costs what an
-                            * independent one does; the SQ counters put 42 % of the wave's cycles into VALU issue, 8 % into scalar
-                            * issue, 29 % into waiting to issue).  Off; kept as the record of the experiment. */
-#endif
-        /* (the restricting down-leg sits at the 512-register limit: with both of its parked slots requested ahead it spills
-         * 72 bytes; it requests DPF of them ahead and reads the rest where they are used) */
-#ifndef MG3D_DP_PREFETCH_RST
-#define MG3D_DP_PREFETCH_RST 0
-#endif
-        constexpr int DPF = MG3D_DP_PREFETCH == 0 ? 0 : RES == 2 ? (MG3D_DP_PREFETCH_RST < DP ? MG3D_DP_PREFETCH_RST : DP) : DP;
-        double ddp[RJ][DPF > 0 ? DPF : 1];
-        if constexpr (DPF > 0) {
-#pragma unroll
-            for (int m = 0; m < DPF; m++) {
-                int idx = ring + (DP - 1 - m); /* slot KV + m was parked at the end of step pl - 1 - m: ring slot (pl - 1 - m) mod DP */
-                idx -= idx >= DP ? DP : 0;
-#pragma unroll
-                for (int rr = 0; rr < RJ; rr++)
-                    ddp[rr][m] = dpk[idx][w * RJ + rr][(PAR + rr) & 1][lane];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
         /* rows of the neighbouring waves, written at the end of the previous step */
         double e_top[STX], e_bot[STX];
 #pragma unroll
@@ -808,13 +761,9 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
                             } else {
                                 /* slot KV + m was parked at the end of step pl - 1 - m, into ring slot (pl - 1 - m) mod DP */
                                 const int m = s - 1 - KV; /* compile-time after unrolling */
-                                if (m < DPF) { /* (compile time) */
-                                    dd = ddp[rr][m < DPF ? m : 0];
-                                } else {
-                                    int idx = ring + (DP - 1 - m);
-                                    idx -= idx >= DP ? DP : 0;
-                                    dd = dpk[idx][w * RJ + rr][X][lane];
-                                }
+                                int idx = ring + (DP - 1 - m);
+                                idx -= idx >= DP ? DP : 0;
+                                dd = dpk[idx][w * RJ + rr][X][lane];
                             }
                         } else {
                             dd = dring[rr][s - DLAG][X];
@@ -942,13 +891,6 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
                 dring[rr][s][0] = dring[rr][s - 1][0];
                 dring[rr][s][1] = dring[rr][s - 1][1];
             }
-        /* PF == 2: request plane i + 2 now, BEHIND this step's stores.  vmcnt counts loads and stores in issue order:
-         * with the request at the top of the step the compiler's wait for the plane the NEXT step needs also covers this
-         * step's younger stores and, piecemeal, the request itself -- a plane was never in flight for a whole step.  Issued
-         * last, the only operations younger than the plane a step waits for are one step's stores and one request:
-         * the wait (vmcnt(12)) leaves exactly that request in flight. */
-        if constexpr (PF == 2 && MG3D_PF2_LATE != 0)
-            load_plane(i + PF, nxt_v[PAR], nxt_d[PAR]);
         /* publish this wave's edge rows for the next step */
 #pragma unroll
         for (int s = 0; s < ST; s++) {
