@@ -589,7 +589,14 @@ def main():
                "counter_bytes": pmc.get(kn),
                "frac_counter": (pmc[kn] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kn in pmc and ms > 0 else None}
         launches_tab.append(row)
-    dom = max((r for r in launches_tab if r["compulsory_bytes"]), key=lambda r: r["ms"] * r["launches"], default=None)
+    # dominant = most time per STEADY-STATE cycle.  The timers sample every (mode - 2)-th cycle starting with the call's first one,
+    # which has no cycle in front of it and takes the ordinary down-leg: in a sample of five the one-launch down-leg then shows four
+    # launches against the up-leg's five although it runs in 19 of the 20 timed cycles -- a kernel seen in all sampled cycles but
+    # one counts as once per cycle
+    tm_ = 1 if args.breakdown else args.timing_mode
+    sampled_ = args.steps if tm_ < 4 else len(range(0, args.steps, tm_ - 2))
+    per_cycle = lambda r: max(1.0, r["launches"] / sampled_) if r["launches"] >= sampled_ - 1 else r["launches"] / sampled_
+    dom = max((r for r in launches_tab if r["compulsory_bytes"]), key=lambda r: r["ms"] * per_cycle(r), default=None)
     if dom is None:
         dom = {"kernel": "none", "what": "no finest-level kernel timed", "ms": 0.0, "launches": 0, "compulsory_bytes": 0,
                "survey_credit_bytes": 0, "counter_bytes": None}
