@@ -567,6 +567,9 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
         const int par = pl & 1;
         unsigned lm = lmask;
         asm volatile("" : "+v"(lm));
+        /* "this column is updatable" as two lane masks formed once a step (the other flags are tested where they are used: as
+         * step-wide masks they cost more scalar registers than the shapes at the limit have): up-leg -1 % */
+        const bool upd_col[2] = {(lm & (unsigned)LM_UPD0) != 0u, (lm & (unsigned)LM_UPD1) != 0u};
         /* current plane <- head of the prefetch queue, then request plane i+PF */
         if constexpr (PF == 2) {
             /* two planes in flight as a RING indexed by the step's parity (a template argument), not a queue that shifts:
@@ -783,7 +786,10 @@ __global__ void __launch_bounds__(NW *WAVE) MG3D_KERNEL_ATTR sweep_kernel(SweepA
         #else
                             const double val = a.sixth * (sum - a.hSq * dd); /* mg_3d.h:438-443 */
         #endif
-                            nwG[g][s] = LM(updu ? (X ? LM_UPD1 : LM_UPD0) : 0) ? val : center;
+                            if constexpr (RES == 2) /* (the restricting shapes sit at the register limit: the step-wide lane masks push them into scratch) */
+                                nwG[g][s] = LM(updu ? (X ? LM_UPD1 : LM_UPD0) : 0) ? val : center;
+                            else
+                                nwG[g][s] = (updu & upd_col[X]) ? val : center;
                             if constexpr (HASTAP) {
                                 /* The tap: the residual norm of the state BETWEEN pass TAPQ and pass TAPQ + 1 without a stage of its
                                  * own.  The colour pass TAPQ has just updated: its residual uses that pass's neighbour sum (as
