@@ -7,7 +7,7 @@ flt = sys.argv[2] if len(sys.argv) > 2 else ""
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
        "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "multigrid_parallel_amd", "csrc"), "-c", src,
-       "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+       "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + sys.argv[3:]  # extra hipcc flags after the filter
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = {}
 rows = []
