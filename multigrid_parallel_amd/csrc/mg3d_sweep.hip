@@ -457,13 +457,14 @@ static int sweep_impl(const mg3d_options &o, const Geom &g, const double *vin, c
 
 /* ---------------------------------------------------------------------------------------------- one launch per leg
  * The legs of a V(2,2) cycle on a level as ONE launch each (mg3d_ctx.hip, "two launches per level"): the level streams
- * through the chip twice per cycle instead of three or four times.  The windows are five to six planes deep: they fit at
- * one wave per SIMD (eight rows per thread, 256 threads, the 512-register budget) with the oldest slots of the d window
- * parked in LDS (DP).
+ * through the chip twice per cycle instead of three or four times.  The windows are five planes deep: they fit two waves
+ * per SIMD (four rows per thread, eight waves) since the prolongation is applied at the end of the step before (MG3D_PRO_LATE),
+ * the wave-edge rows keep one LDS copy (EXS) and two slots of the down-leg's d window are parked in LDS (DP); the first version
+ * needed one wave per SIMD (eight rows, the 512-register budget) and was bound by instruction issue (MG3D_LEG_*_RJ = 8).
  *   down: S = 3 colour passes, black first -- the cycle's first red pass (mg_3d.h:657) is the identity behind the previous
  *         cycle's last red pass --, the residual (:1294) and its full-weighting restriction into the interior of the
  *         coarse right-hand side (:1310).  (S = 4, the leg of a cycle with none in front of it, needs a six-plane window:
- *         180 bytes of scratch, 2.1 ms at 513^3 against 0.66 + 0.49 as two launches -- not instantiated.)  partials != NULL: the sum of
+ *         124 bytes of scratch at two waves per SIMD, 2.1 ms at one -- against 0.66 + 0.49 as two launches: not instantiated.)  partials != NULL: the sum of
  *         diff^2 of the INCOMING state over the colour the first pass updates -- the second half of the previous cycle's
  *         residual norm (:1354), see k_sweep_leg_up.
  *   up:   prolongation (:1331) folded into the loads, four post-smoothing passes black, red, black, red (:1341).
