@@ -154,7 +154,7 @@ __device__ __forceinline__ void st_stream(double *p, double2 o)
 }
 
 /* DP: the DP oldest slots of the d window live in LDS instead of VGPRs (own rows only: written once, read by the thread
- * that wrote them, no barrier) -- what lets a whole leg of the cycle (five-stage windows) stay on chip at one wave per SIMD.
+ * that wrote them, no barrier) -- what lets the down-leg of the cycle (a five-stage window) stay on chip at two waves per SIMD.
  * TAP >= 0: the residual NORM of the state between colour pass TAP and pass TAP + 1 without a stage of its own (see "tap"
  * below; RES == 3 is TAP = S / 2).  TAP = S: only the colour the last pass has updated; TAP = 0: only the colour the
  * first pass is about to update -- the two halves of one norm formed by two consecutive launches. */
