@@ -51,6 +51,10 @@ struct mg3d_ctx {
      * NEXT cycle's down-leg has already run, speculatively: u of the top level is three passes into it and the coarser
      * level's next right-hand side sits in that level's alt buffer; the finished cycle's own u is in the top level's alt */
     int legs_state, legs_slot, legs_npa;
+    /* the last thing that happened to u of the top level is the red pass that ends a V(2,2) cycle and neither u nor d has been
+     * touched since (mg3d_drop_carry clears it: every entry point that reads or writes level data calls that first): the next
+     * cycle's first red pass is the identity also ACROSS calls, its down-leg can be the one launch (mg3d_enqueue_vcycle) */
+    bool red_tail = false;
     bool raw_top; /* a raw device pointer to u or d of the top level was handed out (mg3d_device_view) */
     mg3d_options opt; /* launch / schedule policy (mg3d_options_init at creation, mg3d_ctx_set_option afterwards) */
     bool fused; /* fused sweep kernel (default) or one launch per colour pass (MG3D_NO_FUSE=1) */
@@ -81,5 +85,6 @@ bool mg3d_can_carry(const mg3d_ctx *ctx, int q);
 bool mg3d_can_legs(const mg3d_ctx *ctx, int q);
 /* carried state -> the finished cycle's own u; a no-op (MG3D_OK) otherwise.  An error leaves the carried state in place. */
 int mg3d_drop_carry(mg3d_ctx *ctx);
+int mg3d_drop_carry_keep(mg3d_ctx *ctx); /* the same without clearing red_tail: mg3d_vcycle(s) themselves */
 
 #endif

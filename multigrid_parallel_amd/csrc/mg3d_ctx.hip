@@ -296,6 +296,15 @@ static mg3d_ctx *ctx_new(int L, int iters)
  * mg3d_vcycle(s) continue from the carried state. */
 int mg3d_drop_carry(mg3d_ctx *ctx)
 {
+    /* whoever calls this may go on to change u or d of the top level: the next cycle can no longer rely on its first red
+     * pass being the identity (red_tail, mg3d_enqueue_vcycle); mg3d_vcycle(s) themselves use mg3d_drop_carry_keep */
+    if (ctx)
+        ctx->red_tail = false;
+    return mg3d_drop_carry_keep(ctx);
+}
+
+int mg3d_drop_carry_keep(mg3d_ctx *ctx)
+{
     if (ctx && ctx->legs_state != 0) {
         /* one launch per leg: behind mg3d_vcycle the next cycle's down-leg has run ahead into the alt buffers; the finished
          * cycle's own u is intact in the top level's alt, the coarser level's right-hand side was never touched -- swap
@@ -645,7 +654,7 @@ extern "C" int mg3d_upload(mg3d_ctx *ctx, int field, int level, const double *ho
 
 extern "C" int mg3d_download(mg3d_ctx *ctx, int field, int level, double *host)
 {
-    CHK(mg3d_drop_carry(ctx));
+    CHK(mg3d_drop_carry_keep(ctx)); /* (reads only: the next cycle may still continue behind the last one, see red_tail) */
     CHK(check_field_level(ctx, field, level, "mg3d_download"));
     if (!host)
         return fail(MG3D_ERR_ARG, "mg3d_download: NULL host pointer");
@@ -914,7 +923,7 @@ extern "C" int mg3d_coarse_solve(mg3d_ctx *ctx)
 
 extern "C" int mg3d_l2norm(mg3d_ctx *ctx, int field, int level, double *norm)
 {
-    CHK(mg3d_drop_carry(ctx));
+    CHK(mg3d_drop_carry_keep(ctx)); /* (reads only) */
     CHK(check_field_level(ctx, field, level, "mg3d_l2norm"));
     k_sumsq(ctx->lv[level].g, ctx->lv[level].f[field], ctx->partials, ctx->sumsq, ctx->stream);
     CHK(launch_ok("mg3d_l2norm"));
@@ -1000,18 +1009,25 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out)
     const bool can_legs = mg3d_can_legs(ctx, q);
     const bool can_carry = !can_legs && mg3d_can_carry(ctx, q);
     if ((ctx->carried && !can_carry) || (ctx->legs_state != 0 && !can_legs)) /* e.g. MG3D_NO_CARRY set between two calls: finish the carried cycle, go on plainly */
-        CHK(mg3d_drop_carry(ctx));
+        CHK(mg3d_drop_carry_keep(ctx));
     const bool carry_in = ctx->carried;
     ctx->carried = false;
     const int legs_in = ctx->legs_state;
     ctx->legs_state = 0;
+    /* red_tail: the last thing that happened to u of the top level was the red pass that ends a cycle, and nothing has touched
+     * u or d since (every entry point that could clears the flag through mg3d_drop_carry; not once a raw pointer is out) --
+     * this cycle's first red pass is the identity then, ACROSS calls as inside one: its down-leg is the one launch of three
+     * passes + residual + restriction (no norm half: the finished cycle formed its norm itself) instead of four passes, then
+     * residual + restriction (0.84 against 0.67 + 0.50 ms at 513^3) */
+    const bool red_in = q == L - 1 && legs_in == 0 && !carry_in && ctx->red_tail && can_legs && !ctx->raw_top;
+    ctx->red_tail = false;
     double *const part_a = ctx->partials, *const part_b = ctx->partials + MG3D_MAX_PARTIALS / 2;
     for (int l = q; l >= 1; l--) {
         Level &lev = ctx->lv[l];
         /* (a cycle with no cycle in front of it takes the ordinary down-leg below -- four passes, then residual +
          * restriction: the one-launch form of THAT leg needs a six-plane window, spills 180 bytes at eight rows per thread
          * and took 2.1 ms against 0.66 + 0.49: profiles/r04_bench_kernel_stats_note.txt) */
-        if (l == q && can_legs && legs_in != 0) {
+        if (l == q && can_legs && (legs_in != 0 || red_in)) {
             Level &lc = ctx->lv[l - 1];
             {
                 StageScope t(ctx, l, MG3D_ST_SMOOTH1);
@@ -1027,13 +1043,14 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out)
                     /* behind another cycle: black, red, black (the first red pass is the identity) and the black half of
                      * that cycle's norm, + residual + restriction (:1282 + :1294 + :1310) */
                     const int np = k_sweep_leg_down(ctx->opt, lev.g, lev.f[MG3D_U], lev.f[MG3D_D], lev.alt, lc.g, lc.f[MG3D_D], lev.h,
-                                                    3, part_b, MG3D_MAX_PARTIALS / 2, s);
+                                                    3, red_in ? nullptr : part_b, MG3D_MAX_PARTIALS / 2, s);
                     if (np < 0)
                         return fail(MG3D_ERR_STATE, "one launch per leg: no kernel for the down-leg");
                     double *t2 = lev.f[MG3D_U];
                     lev.f[MG3D_U] = lev.alt;
                     lev.alt = t2;
-                    k_fold2(part_a, ctx->legs_npa, part_b, np, ctx->sumsq + ctx->legs_slot, s);
+                    if (!red_in) /* (behind a cycle of this call: the black half of its norm) */
+                        k_fold2(part_a, ctx->legs_npa, part_b, np, ctx->sumsq + ctx->legs_slot, s);
                 }
             }
             { StageScope t(ctx, l, MG3D_ST_RESIDUAL1); }
@@ -1245,6 +1262,9 @@ int mg3d_enqueue_vcycle(mg3d_ctx *ctx, int q, int slot, int carry_out)
                 CHK(enqueue_residual(ctx, l, 0, slot)); /* :1354; below the top level the value is dropped (:1320) */
         }
     }
+    /* a whole V(2,2) cycle from the top level has ended with its last red pass and nothing runs ahead: see red_in above */
+    if (q == L - 1 && ctx->legs_state == 0 && !ctx->carried && ctx->iters == 2 && ctx->fused)
+        ctx->red_tail = true;
     return launch_ok("mg3d_vcycle");
 }
 
@@ -1258,7 +1278,7 @@ extern "C" int mg3d_vcycle(mg3d_ctx *ctx, int level, double *norm)
         return MG3D_OK;
     }
     if (level != ctx->L - 1)
-        CHK(mg3d_drop_carry(ctx));
+        CHK(mg3d_drop_carry(ctx)); /* (a cycle from a lower level rewrites the levels below the top one only -- but it ends whatever ran ahead) */
     /* One cycle per call is how the reference's solve loop runs (SolverLinSolve, mg_3d.h:1415-1420): the call ends with
      * the launch that also begins the NEXT cycle -- speculatively; whatever the caller does instead of another cycle
      * first puts the finished cycle's own u back (mg3d_drop_carry), and the norm returned is this cycle's either way.
@@ -1286,10 +1306,10 @@ extern "C" int mg3d_vcycles(mg3d_ctx *ctx, int count, double *norms)
     }
     const int batch = ctx->sumsq_slots - 1;
     if (count == 0) /* (behind a single mg3d_vcycle call the first cycle continues from the carried state) */
-        CHK(mg3d_drop_carry(ctx));
+        CHK(mg3d_drop_carry_keep(ctx));
     struct Guard { /* an error return must not leave u of the top level a few passes into a cycle nobody asked for */
         mg3d_ctx *c;
-        ~Guard() { (void)mg3d_drop_carry(c); }
+        ~Guard() { (void)mg3d_drop_carry_keep(c); }
     } guard{ctx};
     for (int done = 0; done < count;) {
         const int nb = (count - done < batch) ? count - done : batch;

@@ -235,6 +235,9 @@ struct mg3d_dist {
     std::vector<Plan> plans_legs[3]; /* one launch per leg: a cycle whose up-leg is one launch (policy | 4), one between two such
                                       * (| 12), the one that only completes its predecessor's norm (| 8) */
     bool legs_pending;             /* the last cycle's norm is half formed (red half in every rank's partials[0 .. legs_npa)) */
+    bool red_tail;                 /* u of the finest level was last changed by the red pass that ends a V(2,2) cycle, all its halo
+                                    * planes are exact and neither u nor d has been touched since (cleared by every entry point that
+                                    * could): the next call's first cycle takes the one-launch down-leg too (csrc/mg3d_ctx.hip, red_tail) */
     bool legs_fixed, legs_on;      /* as carry_fixed / carry_on: agreed between the ranks of an RCCL job at creation */
     int n_legs;                    /* cycles whose up-leg ran as one launch (mg3d_dist_legs_cycles) */
     const std::vector<Plan> *cur;  /* the plan of the cycle being enqueued */
@@ -568,6 +571,7 @@ extern "C" int mg3d_dist_create(int coarse_pts, int num_levels, int smooth_iters
     D->carry_fixed = false;
     D->carry_on = false;
     D->legs_pending = false;
+    D->red_tail = false;
     D->legs_fixed = false;
     D->legs_on = false;
     D->n_legs = 0;
@@ -651,6 +655,7 @@ extern "C" int mg3d_dist_set_option(mg3d_dist *D, const char *key, int value)
 {
     if (!D)
         return fail(MG3D_ERR_ARG, "mg3d_dist_set_option: NULL");
+    D->red_tail = false;
     const int i = mg3d_option_index(key);
     if (i < 0)
         return fail(MG3D_ERR_ARG, "mg3d_dist_set_option: no option \"%s\"", key ? key : "(null)");
@@ -667,6 +672,7 @@ extern "C" int mg3d_dist_set_keep_residual(mg3d_dist *D, int keep)
 {
     if (!D)
         return fail(MG3D_ERR_ARG, "mg3d_dist_set_keep_residual: NULL");
+    D->red_tail = false;
     CHK(dist_refuse_poisoned(D, "mg3d_dist_set_keep_residual"));
     for (auto &R : D->rs)
         R.coarse->keep_r = keep != 0;
@@ -677,6 +683,7 @@ extern "C" int mg3d_dist_build_coarse(mg3d_dist *D, double h_coarse)
 {
     if (!D)
         return fail(MG3D_ERR_ARG, "mg3d_dist_build_coarse: NULL");
+    D->red_tail = false;
     for (auto &R : D->rs)
         CHK(mg3d_ctx_build_coarse(R.coarse, h_coarse));
     return MG3D_OK;
@@ -702,6 +709,7 @@ extern "C" int mg3d_dist_upload(mg3d_dist *D, int field, int level, const double
 {
     if (!D || !host)
         return fail(MG3D_ERR_ARG, "mg3d_dist_upload: NULL");
+    D->red_tail = false;
     if (field == MG3D_U && level == D->L - 1)
         D->poisoned = false; /* u of the finest level, halos included, is replaced: nothing of the failed call is left */
     for (auto &R : D->rs) {
@@ -1075,6 +1083,9 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false, b
     D->cur = legs_out ? &D->plans_legs[legs_in ? 1 : 0] : legs_in ? &D->plans_legs[2] : carry_out ? &D->plans_carry : &D->plans;
     D->carried = false;
     D->legs_pending = false;
+    /* behind a finished cycle of an earlier call (red_tail): the one-launch down-leg without a norm half */
+    const bool red_in = !legs_in && !carry_in && can_legs && D->red_tail;
+    D->red_tail = false;
     DistScope cycle_timer(D, 0, s);
     if (D->timing)
         D->t_cycles++;
@@ -1109,7 +1120,7 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false, b
         const bool keep = D->rs[0].coarse->keep_r;
         std::vector<RestrictTarget> none(D->rs.size(), RestrictTarget{nullptr, nullptr, -1, -1});
         CHK(await_u(D, l));
-        if (l == L - 1 && legs_in) {
+        if (l == L - 1 && (legs_in || red_in)) {
             /* the down-leg as ONE launch over the owned planes: three passes (black first -- the cycle's first red pass is the
              * identity behind the previous cycle's last one), residual, restriction; it reads five planes either side, which
              * the previous cycle's last exchange refreshed.  On its way it forms the black half of the previous cycle's
@@ -1119,17 +1130,19 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false, b
                 SlabLevel &sl = SL(D, R, l);
                 Level &lv = sl.lv;
                 mg3d_ctx *cx = R.coarse;
-                double *part_b = cx->partials + MG3D_MAX_PARTIALS / 2;
+                double *part_b = red_in ? nullptr : cx->partials + MG3D_MAX_PARTIALS / 2;
                 const int npb = k_sweep_leg_down(cx->opt, lv.g, lv.f[MG3D_U], lv.f[MG3D_D], lv.alt, *tgt[ri].gc, tgt[ri].dc, lv.h, 3, part_b,
                                                  MG3D_MAX_PARTIALS / 2, s, sl.own_lo, sl.own_hi, tgt[ri].lo, tgt[ri].hi, sl.own_lo, sl.own_hi);
                 if (npb <= 0)
                     return fail(MG3D_ERR_STATE, "slab sweep: no kernel for the one-launch down-leg on level %d", l);
-                k_fold2(cx->partials, R.legs_npa, part_b, npb, cx->sumsq, s);
+                if (!red_in)
+                    k_fold2(cx->partials, R.legs_npa, part_b, npb, cx->sumsq, s);
                 double *t = lv.f[MG3D_U];
                 lv.f[MG3D_U] = lv.alt;
                 lv.alt = t;
             }
-            CHK(reduce_norm(D, slot - 1));
+            if (!red_in)
+                CHK(reduce_norm(D, slot - 1));
         } else if (l == L - 1 && carry_in) {
             /* the one pre-smoothing pass that is left (black) + residual + restriction in one launch over the owned planes:
              * it reads three planes either side, which the previous cycle's last exchange refreshed */
@@ -1257,6 +1270,10 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false, b
     }
     if (!legs_out)
         CHK(reduce_norm(D, slot));
+    /* a whole V(2,2) cycle has ended the ordinary way: its last pass was red, the exchange behind it leaves all H halo planes
+     * of u exact (plain plan: planes 2..H by exchange, plane 1 as the post-smoother made it) */
+    if (!legs_out && !carry_out && D->nu == 2)
+        D->red_tail = true;
     if (D->phase != (int)(*D->cur)[0].kind.size())
         return fail(MG3D_ERR_STATE, "slab schedule ended after %d of the plan's %d phases", D->phase, (int)(*D->cur)[0].kind.size());
     hipError_t e = hipGetLastError();
@@ -1285,7 +1302,7 @@ extern "C" int mg3d_dist_vcycles(mg3d_dist *D, int count, double *norms)
             if (!ok && (d->carried || d->n_carried != before))
                 d->poisoned = true;
             if (!ok)
-                d->carried = false, d->legs_pending = false; /* (a half-formed norm is simply lost: u itself is a finished cycle's) */
+                d->carried = false, d->legs_pending = false, d->red_tail = false; /* (a half-formed norm is simply lost: u itself is a finished cycle's) */
         }
     } guard{D, carried_before, false};
     for (int done = 0; done < count;) {

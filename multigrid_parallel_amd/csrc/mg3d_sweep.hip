@@ -488,6 +488,17 @@ static int sweep_impl(const mg3d_options &o, const Geom &g, const double *vin, c
 #define MG3D_LEG_DP_DOWN3 2
 #endif
 
+/* the leg launches take the chunk model's choice, never the first-use measurement: their norm-forming variants cannot be measured
+ * (reproducible partial sums), and the variants without a norm half -- the first cycle of a call behind an earlier one, the last
+ * cycle's up-leg -- would otherwise spend ~30 launches of measurement on a geometry whose model choice is the measured best
+ * (MG3D_SWEEP_CI = 247 / 200 / 171 / 129 all slower, profiles/r04_one_launch_per_leg.txt) */
+static mg3d_options leg_options(const mg3d_options &o)
+{
+    mg3d_options q = o;
+    q.v[MG3D_OPT_SWEEP_TUNE] = 0;
+    return q;
+}
+
 static void leg_args(SweepArgs &a, const Geom &g, const double *vin, const double *d, double *vout, double *partials, double h,
                      int c1, int i_lo, int i_hi, int acc_lo, int acc_hi)
 {
@@ -517,6 +528,7 @@ int k_sweep_leg_down(const mg3d_options &o, const Geom &g, const double *vin, co
                      double *partials, int max_partials, hipStream_t s, int acc_lo, int acc_hi, int ic_lo, int ic_hi, int i_lo,
                      int i_hi)
 {
+    const mg3d_options oq = leg_options(o);
     SweepArgs a;
     leg_args(a, g, vin, d, vout, partials, h, S == 4 ? 1 : 0, i_lo, i_hi, acc_lo, acc_hi);
     if (a.i_hi <= a.i_lo)
@@ -527,14 +539,14 @@ int k_sweep_leg_down(const mg3d_options &o, const Geom &g, const double *vin, co
     a.ic_hi = ic_hi >= 0 ? ic_hi : gc.ni;
 #if MG3D_LEG_DOWN_RJ == 4
     if (S == 3 && partials)
-        return launch_sweep<3, 2, 4, 8, 1, false, true, MG3D_LEG_DP_DOWN3, 0>(o, a, max_partials, s);
+        return launch_sweep<3, 2, 4, 8, 1, false, true, MG3D_LEG_DP_DOWN3, 0>(oq, a, max_partials, s);
     if (S == 3)
-        return launch_sweep<3, 2, 4, 8, 1, false, true, MG3D_LEG_DP_DOWN3, -1>(o, a, max_partials, s);
+        return launch_sweep<3, 2, 4, 8, 1, false, true, MG3D_LEG_DP_DOWN3, -1>(oq, a, max_partials, s);
 #else
     if (S == 3 && partials)
-        return launch_sweep<3, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN3, 0>(o, a, max_partials, s);
+        return launch_sweep<3, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN3, 0>(oq, a, max_partials, s);
     if (S == 3)
-        return launch_sweep<3, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN3, -1>(o, a, max_partials, s);
+        return launch_sweep<3, 2, 8, 4, 1, false, true, MG3D_LEG_DP_DOWN3, -1>(oq, a, max_partials, s);
 #endif
     return -1;
 }
@@ -544,6 +556,7 @@ int k_sweep_leg_up(const mg3d_options &o, const Geom &g, const double *vin, cons
 {
     if ((g.nj & 1) == 0)
         return -1;
+    const mg3d_options oq = leg_options(o);
     SweepArgs a;
     leg_args(a, g, vin, d, vout, partials, h, 0, i_lo, i_hi, acc_lo, acc_hi);
     if (a.i_hi <= a.i_lo)
@@ -553,12 +566,12 @@ int k_sweep_leg_up(const mg3d_options &o, const Geom &g, const double *vin, cons
     a.edge = edge;
 #if MG3D_LEG_UP_RJ == 4
     if (partials)
-        return launch_sweep<4, 0, 4, 8, 1, true, true, MG3D_LEG_DP_UP, 4>(o, a, max_partials, s);
-    return launch_sweep<4, 0, 4, 8, 1, true, true, MG3D_LEG_DP_UP, -1>(o, a, max_partials, s);
+        return launch_sweep<4, 0, 4, 8, 1, true, true, MG3D_LEG_DP_UP, 4>(oq, a, max_partials, s);
+    return launch_sweep<4, 0, 4, 8, 1, true, true, MG3D_LEG_DP_UP, -1>(oq, a, max_partials, s);
 #else
     if (partials)
-        return launch_sweep<4, 0, 8, 4, 1, true, true, MG3D_LEG_DP_UP, 4>(o, a, max_partials, s);
-    return launch_sweep<4, 0, 8, 4, 1, true, true, MG3D_LEG_DP_UP, -1>(o, a, max_partials, s);
+        return launch_sweep<4, 0, 8, 4, 1, true, true, MG3D_LEG_DP_UP, 4>(oq, a, max_partials, s);
+    return launch_sweep<4, 0, 8, 4, 1, true, true, MG3D_LEG_DP_UP, -1>(oq, a, max_partials, s);
 #endif
 }
 

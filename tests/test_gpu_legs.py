@@ -168,3 +168,51 @@ def test_right_hand_side_and_scale_do_not_matter(monkeypatch):
                 res.append((n, s.download(MG3D_U, L - 1), s.download(MG3D_D, L - 2)))
         assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]), scale
         np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-12)
+
+
+def test_next_call_continues_behind_the_last_cycle_unless_the_state_was_touched(monkeypatch):
+    """A cycle's first red pass is the identity behind the red pass that ended the cycle before it -- also across two mg3d_vcycles
+    calls, as long as nothing has touched u or d of the top level in between: the second call's first cycle then takes the
+    one-launch down-leg too (no four-pass launch, no residual + restriction launch).  An upload in between ends that: the next
+    cycle runs all four pre-smoothing passes -- on a u whose red points no longer are what a red pass would make them -- and
+    equals the plain schedule started from the same state, bit for bit."""
+    c, L = 9, 5
+    top = L - 1
+    with M.Solver(c, L, 2) as s:
+        _legs(s, True)
+        s.setup_test_problem()
+        s.vcycles(2)
+        s.timing_enable(1)
+        n2 = s.vcycles(3)
+        kt = {kn: n for (lvl, kn), (n, _) in s.kernel_times().items() if lvl == top}
+        assert kt == {"leg_up": 3, "leg_down": 3, "residual": 1}, kt  # (residual: the last cycle's norm-only launch)
+        want_norms, want_u, _, _ = O.run_problem(c, L, 2, 5)
+        assert np.array_equal(s.download(MG3D_U, top), want_u)
+        np.testing.assert_allclose(n2, want_norms[2:], rtol=norm_rtol(s.N))
+        # a download in between reads only: the next call still continues behind the last cycle
+        s.timing_reset()
+        s.vcycles(1)
+        kt = {kn: n for (lvl, kn), (n, _) in s.kernel_times().items() if lvl == top}
+        assert kt == {"leg_up": 1, "leg_down": 1, "residual": 1}, kt
+        assert np.array_equal(s.download(MG3D_U, top), O.run_problem(c, L, 2, 6)[1])
+        # touch the state: every interior point moved a little, red ones included
+        u = s.download(MG3D_U, top)
+        N = s.N
+        u3 = u.reshape(N, N, N)
+        rng = np.random.default_rng(5)
+        u3[1:-1, 1:-1, 1:-1] += 1e-3 * rng.standard_normal((N - 2, N - 2, N - 2))
+        s.upload(MG3D_U, top, u)
+        s.timing_reset()
+        got_norms = s.vcycles(2)
+        kt = {kn: n for (lvl, kn), (n, _) in s.kernel_times().items() if lvl == top}
+        assert kt.get("sweep4", 0) == 1 and kt.get("leg_down", 0) == 1, kt
+        got_u = s.download(MG3D_U, top)
+        d = s.download(MG3D_D, top)
+    with M.Solver(c, L, 2) as p:
+        _legs(p, False)
+        p.setup_test_problem()
+        p.upload(MG3D_U, top, u)
+        p.upload(MG3D_D, top, d)
+        plain_norms = p.vcycles(2)
+        assert np.array_equal(p.download(MG3D_U, top), got_u)
+    np.testing.assert_allclose(got_norms, plain_norms, rtol=1e-12)
