@@ -1184,6 +1184,7 @@ static int dist_enqueue_vcycle(mg3d_dist *D, int slot, bool carry_out = false, b
                 continue;
             Level &lc = R.coarse->lv[ld - 1];
             (void)hipMemsetAsync(lc.f[MG3D_U], 0, lc.elems * sizeof(double), s);
+            R.coarse->red_tail = false; /* u and d of the context's top level were rewritten behind its back (here; the restriction) */
             if (ld - 1 == 0)
                 CHK(mg3d_coarse_solve(R.coarse));
             else
