@@ -437,8 +437,14 @@ static int sweep_impl(const mg3d_options &o, const Geom &g, const double *vin, c
         return -1;
     if (S == 4 && residual)
         return dispatch<4, 1>(o, a, opt_cfg(o, {6, 4, 2}), max_partials, s);
-    if (S == 4 && !residual)
-        return dispatch<4, 0>(o, a, opt_cfg(o, small ? SweepCfg{2, 8, 2} : SweepCfg{4, 8, 1}), max_partials, s);
+    if (S == 4 && !residual) {
+        /* from the zero guess on the levels between 66 and 300 points per side (129^3, 257^3: a step is paid in latency, the
+         * launch has a CU per block and little else): two rows a thread, SIXTEEN waves -- the same 32-row tile at four waves
+         * per SIMD (128 VGPRs, no scratch): 257^3 80 -> 71-74 us, 129^3 25 -> 22 us; 65^3 and below 11.5 -> 14 (the eight-wave
+         * two-row shape stays), 513^3 425 -> 420 (the four-row shape stays); kernel trace, round 4 */
+        const bool mid = vin == nullptr && g.N > 65 && g.N <= 300;
+        return dispatch<4, 0>(o, a, opt_cfg(o, mid ? SweepCfg{2, 16, 1} : small ? SweepCfg{2, 8, 2} : SweepCfg{4, 8, 1}), max_partials, s);
+    }
     if (S == 2 && residual) {
         /* the norm alone (the top level's second post-smoothing launch): a shape without the code that assembles r */
         const SweepCfg c = opt_cfg(o, {4, 8, 1});
